@@ -1,0 +1,315 @@
+"""ctypes front-end of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+It loads oracle/libchq_oracle.so (built by oracle/Makefile from chq_oracle.c, a plain-C restatement of
+the reference's record_utils path -- see chq_oracle.h) and exposes the reference's three entry points
+on pyarrow RecordBatches:
+
+    compute_value(rec, table_aliases, expr)   -> (pyarrow.Array, is_scalar)   compute_value.rs:57-61
+    filter_record(rec, table_aliases, expr)   -> pyarrow.RecordBatch           filter_record.rs:21-25
+    project_record(fields, rec, table_aliases)-> pyarrow.RecordBatch           record_projection.rs:16-20
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import pyarrow as pa
+
+from chapterhouseqe_amd import sqlast as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libchq_oracle.so")
+
+OC_TYPES = [pa.bool_(), pa.int8(), pa.int16(), pa.int32(), pa.int64(), pa.uint8(), pa.uint16(), pa.uint32(),
+            pa.uint64(), pa.float16(), pa.float32(), pa.float64(), pa.utf8()]
+_WIDTH = [0, 1, 2, 4, 8, 1, 2, 4, 8, 2, 4, 8, 0]
+OC_UTF8, OC_BOOL = 12, 0
+
+_OPS = {A.BinaryOperator.And: 0, A.BinaryOperator.Or: 1, A.BinaryOperator.Plus: 2, A.BinaryOperator.Minus: 3,
+        A.BinaryOperator.Multiply: 4, A.BinaryOperator.Divide: 5, A.BinaryOperator.Modulo: 6,
+        A.BinaryOperator.Eq: 7, A.BinaryOperator.NotEq: 8, A.BinaryOperator.Gt: 9, A.BinaryOperator.GtEq: 10,
+        A.BinaryOperator.Lt: 11, A.BinaryOperator.LtEq: 12}
+_OP_OTHER = 13
+
+
+class OracleError(Exception):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+        self.message = message
+
+
+def build() -> str:
+    """(Re)build the oracle shared library with the committed Makefile."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+class _Item(C.Structure):
+    _fields_ = [("kind", C.c_int), ("expr", C.c_void_p), ("alias", C.c_char_p)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "chq_oracle.c")):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    vp, i64, cp = C.c_void_p, C.c_int64, C.c_char_p
+    sig = {
+        "oc_expr_identifier": (vp, [cp]), "oc_expr_compound_identifier": (vp, [C.POINTER(cp), C.c_int]),
+        "oc_expr_number": (vp, [cp, C.c_int]), "oc_expr_boolean": (vp, [C.c_int]), "oc_expr_string": (vp, [cp, i64]),
+        "oc_expr_value_other": (vp, [cp]), "oc_expr_binary": (vp, [C.c_int, cp, vp, vp]), "oc_expr_nested": (vp, [vp]),
+        "oc_expr_other": (vp, [cp]), "oc_expr_free": (None, [vp]),
+        "oc_batch_new": (vp, [C.c_int, i64]),
+        "oc_batch_set_column": (C.c_int, [vp, C.c_int, cp, C.c_int, C.c_int, vp, i64, vp, vp, i64]),
+        "oc_batch_set_aliases": (C.c_int, [vp, C.c_int, C.POINTER(cp), C.c_int]),
+        "oc_batch_truncate_aliases": (None, [vp, C.c_int]), "oc_batch_free": (None, [vp]),
+        "oc_batch_num_columns": (C.c_int, [vp]), "oc_batch_num_rows": (i64, [vp]),
+        "oc_batch_field_name": (cp, [vp, C.c_int]), "oc_batch_field_nullable": (C.c_int, [vp, C.c_int]),
+        "oc_batch_column": (vp, [vp, C.c_int]),
+        "oc_array_type": (C.c_int, [vp]), "oc_array_length": (i64, [vp]), "oc_array_null_count": (i64, [vp]),
+        "oc_array_values": (vp, [vp]), "oc_array_bit_offset": (i64, [vp]), "oc_array_data": (vp, [vp]),
+        "oc_array_validity": (vp, [vp]), "oc_array_validity_bit_offset": (i64, [vp]), "oc_array_free": (None, [vp]),
+        "oc_compute_value": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_int), cp, C.c_int]),
+        "oc_filter_record": (C.c_int, [vp, vp, C.POINTER(vp), cp, C.c_int]),
+        "oc_project_record": (C.c_int, [C.POINTER(_Item), C.c_int, vp, C.POINTER(vp), cp, C.c_int]),
+        "oc_filter_table_batched": (C.c_int, [vp, vp, i64, C.POINTER(i64), C.POINTER(C.c_double), cp, C.c_int]),
+        "oc_filter_project_table_batched": (C.c_int, [vp, vp, C.POINTER(_Item), C.c_int, i64, C.POINTER(i64),
+                                                      C.POINTER(C.c_double), cp, C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+# ------------------------------------------------------------------------------------ expr -> oc_expr
+def _expr_to_c(e: A.Expr):
+    L = lib()
+    if isinstance(e, A.Nested):
+        return L.oc_expr_nested(_expr_to_c(e.expr))
+    if isinstance(e, A.BinaryOp):
+        return L.oc_expr_binary(_OPS.get(e.op, _OP_OTHER), e.op.value.encode(), _expr_to_c(e.left), _expr_to_c(e.right))
+    if isinstance(e, A.ValueExpr):
+        v = e.value
+        if isinstance(v, A.Number):
+            return L.oc_expr_number(v.text.encode(), int(v.long))
+        if isinstance(v, A.Boolean):
+            return L.oc_expr_boolean(int(v.value))
+        if isinstance(v, A.SingleQuotedString):
+            b = v.value.encode()
+            return L.oc_expr_string(b, len(b))
+        return L.oc_expr_value_other(v.debug.encode())
+    if isinstance(e, A.Identifier):
+        return L.oc_expr_identifier(e.ident.value.encode())
+    if isinstance(e, A.CompoundIdentifier):
+        arr = (C.c_char_p * max(1, len(e.idents)))(*[i.value.encode() for i in e.idents])
+        return L.oc_expr_compound_identifier(arr, len(e.idents))
+    if isinstance(e, A.UnsupportedExpr):
+        return L.oc_expr_other(e.debug.encode())
+    raise TypeError(f"not an Expr: {e!r}")
+
+
+# ------------------------------------------------------------------------------------ batches
+_DUMMY = C.create_string_buffer(16)
+
+
+class _Batch:
+    """oc_batch handle plus the pyarrow buffers it borrows."""
+
+    def __init__(self, rec: pa.RecordBatch, table_aliases: Optional[Sequence[Sequence[str]]]):
+        L = lib()
+        self.keep = [rec]
+        self.h = L.oc_batch_new(rec.num_columns, rec.num_rows)
+        for i in range(rec.num_columns):
+            col = rec.column(i)
+            fld = rec.schema.field(i)
+            try:
+                t = OC_TYPES.index(col.type)
+            except ValueError:
+                raise OracleError(30, f"type {col.type} is outside the oracle's scope")
+            bufs = col.buffers()
+            off = col.offset
+            validity = bufs[0].address if bufs[0] is not None else None
+            data, bit_offset = None, 0
+            if t == OC_BOOL:
+                values, bit_offset = bufs[1].address, off
+            elif t == OC_UTF8:
+                values = bufs[1].address + 4 * off
+                data = bufs[2].address if (len(bufs) > 2 and bufs[2] is not None and bufs[2].size > 0) else C.addressof(_DUMMY)
+            else:
+                values = bufs[1].address + _WIDTH[t] * off
+            rc = L.oc_batch_set_column(self.h, i, fld.name.encode(), t, int(fld.nullable), values, bit_offset, data,
+                                       validity, off)
+            if rc:
+                raise OracleError(rc, "oc_batch_set_column failed")
+        if table_aliases is not None:
+            for i, al in enumerate(table_aliases[: rec.num_columns]):
+                arr = (C.c_char_p * max(1, len(al)))(*[a.encode() for a in al])
+                L.oc_batch_set_aliases(self.h, i, arr, len(al))
+            if len(table_aliases) < rec.num_columns:
+                L.oc_batch_truncate_aliases(self.h, len(table_aliases))
+
+    def close(self):
+        if self.h:
+            lib().oc_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+def _buf(addr: int, nbytes: int) -> pa.Buffer:
+    return pa.py_buffer(C.string_at(addr, nbytes) if nbytes > 0 else b"")
+
+
+def _array_to_pa(h) -> pa.Array:
+    L = lib()
+    t = L.oc_array_type(h)
+    n = L.oc_array_length(h)
+    nc = L.oc_array_null_count(h)
+    typ = OC_TYPES[t]
+    vaddr = L.oc_array_validity(h)
+    validity = None
+    if vaddr and nc > 0:
+        assert L.oc_array_validity_bit_offset(h) == 0
+        validity = _buf(vaddr, (n + 7) // 8)
+    values = L.oc_array_values(h)
+    if t == OC_BOOL:
+        assert L.oc_array_bit_offset(h) == 0
+        return pa.Array.from_buffers(typ, n, [validity, _buf(values, (n + 7) // 8)], null_count=nc)
+    if t == OC_UTF8:
+        offs = C.string_at(values, 4 * (n + 1))
+        last = int.from_bytes(offs[-4:], "little", signed=True)
+        data = _buf(L.oc_array_data(h), last)
+        return pa.Array.from_buffers(typ, n, [validity, pa.py_buffer(offs), data], null_count=nc)
+    return pa.Array.from_buffers(typ, n, [validity, _buf(values, n * _WIDTH[t])], null_count=nc)
+
+
+def _batch_to_pa(h) -> pa.RecordBatch:
+    L = lib()
+    ncols = L.oc_batch_num_columns(h)
+    arrays, fields = [], []
+    for i in range(ncols):
+        arr = _array_to_pa(L.oc_batch_column(h, i))
+        arrays.append(arr)
+        fields.append(pa.field(L.oc_batch_field_name(h, i).decode(), arr.type, bool(L.oc_batch_field_nullable(h, i))))
+    if ncols == 0:
+        return pa.RecordBatch.from_arrays([], schema=pa.schema([]))
+    return pa.RecordBatch.from_arrays(arrays, schema=pa.schema(fields))
+
+
+def _items_to_c(fields: Sequence[A.SelectItem]):
+    L = lib()
+    items = (_Item * max(1, len(fields)))()
+    exprs = []
+    for i, f in enumerate(fields):
+        if isinstance(f, A.Wildcard):
+            items[i].kind = 0
+        elif isinstance(f, A.QualifiedWildcard):
+            items[i].kind = 1
+        elif isinstance(f, A.UnnamedExpr):
+            items[i].kind = 2
+            items[i].expr = _expr_to_c(f.expr)
+            exprs.append(items[i].expr)
+        elif isinstance(f, A.ExprWithAlias):
+            items[i].kind = 3
+            items[i].expr = _expr_to_c(f.expr)
+            items[i].alias = f.alias.value.encode()
+            exprs.append(items[i].expr)
+        else:
+            raise TypeError(f"not a SelectItem: {f!r}")
+    return items, exprs
+
+
+# ------------------------------------------------------------------------------------ the path
+def compute_value(rec: pa.RecordBatch, table_aliases, expr: A.Expr) -> Tuple[pa.Array, bool]:
+    L = lib()
+    b = _Batch(rec, table_aliases)
+    e = _expr_to_c(expr)
+    out, sc, err = C.c_void_p(), C.c_int(0), C.create_string_buffer(512)
+    try:
+        rc = L.oc_compute_value(b.h, e, C.byref(out), C.byref(sc), err, 512)
+        if rc:
+            raise OracleError(rc, err.value.decode(errors="replace"))
+        try:
+            return _array_to_pa(out), bool(sc.value)
+        finally:
+            L.oc_array_free(out)
+    finally:
+        L.oc_expr_free(e)
+        b.close()
+
+
+def filter_record(rec: pa.RecordBatch, table_aliases, expr: A.Expr) -> pa.RecordBatch:
+    L = lib()
+    b = _Batch(rec, table_aliases)
+    e = _expr_to_c(expr)
+    out, err = C.c_void_p(), C.create_string_buffer(512)
+    try:
+        rc = L.oc_filter_record(b.h, e, C.byref(out), err, 512)
+        if rc:
+            raise OracleError(rc, err.value.decode(errors="replace"))
+        try:
+            res = _batch_to_pa(out)
+            if res.num_columns == 0:
+                return res
+            return res
+        finally:
+            L.oc_batch_free(out)
+    finally:
+        L.oc_expr_free(e)
+        b.close()
+
+
+def project_record(fields: Sequence[A.SelectItem], rec: pa.RecordBatch, table_aliases) -> pa.RecordBatch:
+    L = lib()
+    b = _Batch(rec, table_aliases)
+    items, exprs = _items_to_c(fields)
+    out, err = C.c_void_p(), C.create_string_buffer(512)
+    try:
+        rc = L.oc_project_record(items, len(fields), b.h, C.byref(out), err, 512)
+        if rc:
+            raise OracleError(rc, err.value.decode(errors="replace"))
+        try:
+            return _batch_to_pa(out)
+        finally:
+            L.oc_batch_free(out)
+    finally:
+        for e in exprs:
+            L.oc_expr_free(e)
+        b.close()
+
+
+def filter_table_batched(rec: pa.RecordBatch, table_aliases, expr: A.Expr, batch_rows: int = 10_000,
+                         fields: Optional[Sequence[A.SelectItem]] = None) -> Tuple[int, float]:
+    """CPU baseline: the reference's per-batch loop (filter_task.rs:86-125) on one thread.
+    Returns (rows kept, seconds)."""
+    L = lib()
+    b = _Batch(rec, table_aliases)
+    e = _expr_to_c(expr)
+    rows, secs, err = C.c_int64(0), C.c_double(0), C.create_string_buffer(512)
+    exprs: List = []
+    try:
+        if fields is None:
+            rc = L.oc_filter_table_batched(b.h, e, batch_rows, C.byref(rows), C.byref(secs), err, 512)
+        else:
+            items, exprs = _items_to_c(fields)
+            rc = L.oc_filter_project_table_batched(b.h, e, items, len(fields), batch_rows, C.byref(rows), C.byref(secs), err, 512)
+        if rc:
+            raise OracleError(rc, err.value.decode(errors="replace"))
+        return rows.value, secs.value
+    finally:
+        for x in exprs:
+            L.oc_expr_free(x)
+        L.oc_expr_free(e)
+        b.close()
