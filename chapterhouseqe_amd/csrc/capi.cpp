@@ -1,0 +1,300 @@
+// capi.cpp -- the extern "C" surface declared in include/chq.h.
+#include <cstring>
+#include <new>
+
+#include "engine.hpp"
+
+using namespace chq;
+
+struct chq_ctx { Context c; };
+struct chq_expr { Expr e; };
+
+namespace {
+
+template <typename F>
+chq_status guarded(chq_ctx* ctx, F&& f) {
+  try {
+    f();
+    if (ctx) ctx->c.last_error.clear();
+    return CHQ_OK;
+  } catch (const ChqError& e) {
+    if (ctx) ctx->c.last_error = e.msg;
+    return (chq_status)e.code;
+  } catch (const std::bad_alloc&) {
+    if (ctx) ctx->c.last_error = "out of host memory";
+    return CHQ_ERR_OUT_OF_MEMORY;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->c.last_error = e.what();
+    return CHQ_ERR_DEVICE;
+  }
+}
+
+void mark_released(ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (out) { memset(out, 0, sizeof(*out)); }
+  if (out_schema) { memset(out_schema, 0, sizeof(*out_schema)); }
+}
+
+void finish(Context& c, Batch&& result_dev, int out_device, ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (out_device == ARROW_DEVICE_ROCM) export_batch(std::move(result_dev), ARROW_DEVICE_ROCM, out, out_schema);
+  else if (out_device == ARROW_DEVICE_CPU) { Batch h = to_host(c, result_dev); export_batch(std::move(h), ARROW_DEVICE_CPU, out, out_schema); }
+  else throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+}
+
+void require(const void* p, const char* what) { if (!p) throw ChqError{CHQ_ERR_INVALID_HANDLE, std::string("null ") + what}; }
+
+}  // namespace
+
+extern "C" {
+
+int chq_abi_version(void) { return CHQ_ABI_VERSION; }
+
+const char* chq_status_name(chq_status s) {
+  switch (s) {
+    case CHQ_OK: return "Ok";
+    case CHQ_ERR_VALUE_TYPE_NOT_IMPLEMENTED: return "ComputeValueError::ValueTypeNotImplemented";
+    case CHQ_ERR_EXPRESSION_TYPE_NOT_IMPLEMENTED: return "ComputeValueError::ExpressionTypeNotImplemented";
+    case CHQ_ERR_BINARY_OPERATOR_NOT_IMPLEMENTED: return "ComputeValueError::BinaryOperatorNotImplemented";
+    case CHQ_ERR_BINARY_OPERATION_CAST_FAILED: return "ComputeValueError::BinaryOperatinCastFailed";
+    case CHQ_ERR_FAILED_TO_PARSE_AS_AN_INTEGER: return "ComputeValueError::FailedToParseAsAnInteger";
+    case CHQ_ERR_FAILED_TO_PARSE_AS_A_FLOAT: return "ComputeValueError::FailedToParseAsAFloat";
+    case CHQ_ERR_COLUMN_NOT_FOUND: return "ComputeValueError::ColumnNotFound";
+    case CHQ_ERR_IDENTIFIER_NOT_FOUND: return "ComputeValueError::IdentifierNotFound";
+    case CHQ_ERR_UNSUPPORTED_TYPE_COERSION: return "ComputeValueError::UnsupportedTypeCoersionForOperationBetweenTypes";
+    case CHQ_ERR_CAST_TO_BOOLEAN_ARRAY_FAILED: return "FilterRecordError::CastToBooleanArrayFailedForArrayType";
+    case CHQ_ERR_PROJECT_NOT_IMPLEMENTED: return "ProjectRecordError::NotImplemented";
+    case CHQ_ERR_ARROW_ARITHMETIC_OVERFLOW: return "ArrowError::ArithmeticOverflow";
+    case CHQ_ERR_ARROW_DIVIDE_BY_ZERO: return "ArrowError::DivideByZero";
+    case CHQ_ERR_ARROW_INVALID_ARGUMENT: return "ArrowError::InvalidArgumentError";
+    case CHQ_ERR_ARROW_COMPUTE: return "ArrowError::ComputeError";
+    case CHQ_ERR_ARROW_CAST: return "ArrowError::CastError";
+    case CHQ_ERR_NOT_SUPPORTED: return "NotSupported";
+    case CHQ_ERR_INVALID_HANDLE: return "InvalidHandle";
+    case CHQ_ERR_DEVICE: return "DeviceError";
+    case CHQ_ERR_OUT_OF_MEMORY: return "OutOfMemory";
+  }
+  return "Unknown";
+}
+
+chq_status chq_ctx_create(int device_id, void* hip_stream, chq_ctx** out) {
+  if (!out) return CHQ_ERR_INVALID_HANDLE;
+  *out = nullptr;
+  chq_ctx* ctx = new (std::nothrow) chq_ctx();
+  if (!ctx) return CHQ_ERR_OUT_OF_MEMORY;
+  chq_status st = guarded(ctx, [&] {
+    int n = 0;
+    check_hip(hipGetDeviceCount(&n), "hipGetDeviceCount");
+    if (n <= 0 || device_id < 0 || device_id >= n) throw ChqError{CHQ_ERR_DEVICE, "no usable GPU for device id " + std::to_string(device_id)};
+    check_hip(hipSetDevice(device_id), "hipSetDevice");
+    hipDeviceProp_t prop;
+    check_hip(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties");
+    ctx->c.device = device_id;
+    ctx->c.num_cus = prop.multiProcessorCount;
+    if (hip_stream) { ctx->c.stream = (hipStream_t)hip_stream; ctx->c.own_stream = false; }
+    else { check_hip(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking), "hipStreamCreate"); ctx->c.own_stream = true; }
+  });
+  if (st != CHQ_OK) { delete ctx; return st; }
+  *out = ctx;
+  return CHQ_OK;
+}
+
+void chq_ctx_destroy(chq_ctx* ctx) { delete ctx; }
+const char* chq_ctx_last_error(const chq_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : "null context"; }
+void* chq_ctx_stream(const chq_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+void chq_ctx_last_stats(const chq_ctx* ctx, chq_call_stats* out) { if (ctx && out) *out = ctx->c.stats; }
+
+chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return CHQ_ERR_INVALID_HANDLE;
+  return guarded(ctx, [&] {
+    std::string k(key);
+    if (k == "tile_kind") { if (value < -1 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "tile_kind must be -1..2"}; ctx->c.opt_tile_kind = value; }
+    else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
+    else if (k == "trim_pool") DevicePool::instance().trim();
+    else throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "unknown option: " + k};
+  });
+}
+
+// ---- expressions ------------------------------------------------------------------------------------
+static chq_expr* new_expr(Expr::Kind k) { chq_expr* e = new (std::nothrow) chq_expr(); if (e) e->e.kind = k; return e; }
+chq_expr* chq_expr_identifier(const char* name) { chq_expr* e = new_expr(Expr::IDENT); if (e) e->e.text = name ? name : ""; return e; }
+chq_expr* chq_expr_compound_identifier(const char* const* parts, int n) {
+  chq_expr* e = new_expr(Expr::COMPOUND);
+  if (e) for (int i = 0; i < n; ++i) e->e.parts.push_back(parts[i] ? parts[i] : "");
+  return e;
+}
+chq_expr* chq_expr_number(const char* text, int is_long) { chq_expr* e = new_expr(Expr::NUMBER); if (e) { e->e.text = text ? text : ""; e->e.flag = is_long != 0; } return e; }
+chq_expr* chq_expr_boolean(int value) { chq_expr* e = new_expr(Expr::BOOLEAN); if (e) e->e.flag = value != 0; return e; }
+chq_expr* chq_expr_single_quoted_string(const char* bytes, int64_t len) {
+  chq_expr* e = new_expr(Expr::STRING);
+  if (e && bytes && len > 0) e->e.text.assign(bytes, (size_t)len);
+  return e;
+}
+chq_expr* chq_expr_unsupported_value(const char* debug) { chq_expr* e = new_expr(Expr::VALUE_OTHER); if (e) e->e.text = debug ? debug : ""; return e; }
+chq_expr* chq_expr_binary_op(chq_expr* left, chq_binary_operator op, const char* op_debug, chq_expr* right) {
+  chq_expr* e = new_expr(Expr::BINARY);
+  if (!e || !left || !right) { chq_expr_free(left); chq_expr_free(right); delete e; return nullptr; }
+  e->e.op = (int)op; e->e.text = op_debug ? op_debug : "";
+  // the wrapper structs own nothing but the Expr: move the trees in and drop the shells
+  e->e.l.reset(new Expr(std::move(left->e))); e->e.r.reset(new Expr(std::move(right->e)));
+  delete left; delete right;
+  return e;
+}
+chq_expr* chq_expr_nested(chq_expr* inner) {
+  chq_expr* e = new_expr(Expr::NESTED);
+  if (!e || !inner) { chq_expr_free(inner); delete e; return nullptr; }
+  e->e.l.reset(new Expr(std::move(inner->e)));
+  delete inner;
+  return e;
+}
+chq_expr* chq_expr_unsupported(const char* debug) { chq_expr* e = new_expr(Expr::OTHER); if (e) e->e.text = debug ? debug : ""; return e; }
+void chq_expr_free(chq_expr* e) { delete e; }
+
+// ---- the path -------------------------------------------------------------------------------------------
+chq_status chq_filter_record(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema,
+                             const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
+                             ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(expr, "expression"); require(out, "output array"); require(out_schema, "output schema");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    Batch dev = to_device(ctx->c, in);
+    auto pcols = plan_columns(dev, table_aliases);
+    Batch res = filter_record(ctx->c, dev, pcols, expr->e);
+    finish(ctx->c, std::move(res), out_device, out, out_schema);
+  });
+}
+
+chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n_fields, const ArrowDeviceArray* rec,
+                              const ArrowSchema* schema, const chq_table_aliases* table_aliases, int out_device,
+                              ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema");
+    if (n_fields > 0) require(fields, "select items");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    Batch dev = to_device(ctx->c, in);
+    auto pcols = plan_columns(dev, table_aliases);
+    std::vector<chq_select_item> items(fields, fields + (n_fields > 0 ? n_fields : 0));
+    Batch res = project_record(ctx->c, items, dev, pcols);
+    finish(ctx->c, std::move(res), out_device, out, out_schema);
+  });
+}
+
+chq_status chq_compute_value(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema,
+                             const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
+                             ArrowDeviceArray* out, ArrowSchema* out_schema, int* out_is_scalar) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(expr, "expression"); require(out, "output array"); require(out_schema, "output schema");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    Batch dev = to_device(ctx->c, in);
+    auto pcols = plan_columns(dev, table_aliases);
+    bool sc = false;
+    Column col = compute_value(ctx->c, dev, pcols, expr->e, &sc);
+    if (out_is_scalar) *out_is_scalar = sc ? 1 : 0;
+    // reuse the batch path for the host copy
+    Batch one; one.nrows = col.length; one.on_device = true; one.device_id = ctx->c.device;
+    one.cols.push_back(std::move(col));
+    if (out_device == ARROW_DEVICE_CPU) { Batch h = to_host(ctx->c, one); export_single_column(std::move(h.cols[0]), false, -1, out, out_schema); }
+    else if (out_device == ARROW_DEVICE_ROCM) export_single_column(std::move(one.cols[0]), true, ctx->c.device, out, out_schema);
+    else throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+  });
+}
+
+chq_status chq_filter_project_record(chq_ctx* ctx, const chq_expr* predicate, const chq_select_item* fields, int n_fields,
+                                     const ArrowDeviceArray* rec, const ArrowSchema* schema,
+                                     const chq_table_aliases* table_aliases, int out_device, ArrowDeviceArray* out,
+                                     ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(predicate, "predicate"); require(out, "output array"); require(out_schema, "output schema");
+    if (n_fields > 0) require(fields, "select items");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    Batch dev = to_device(ctx->c, in);
+    auto pcols = plan_columns(dev, table_aliases);
+    Batch filtered = filter_record(ctx->c, dev, pcols, predicate->e);   // stays in HBM
+    chq_call_stats fs = ctx->c.stats;
+    auto pcols2 = plan_columns(filtered, table_aliases);
+    std::vector<chq_select_item> items(fields, fields + (n_fields > 0 ? n_fields : 0));
+    Batch res = project_record(ctx->c, items, filtered, pcols2);
+    fs.launches += ctx->c.stats.launches;
+    ctx->c.stats = fs;
+    finish(ctx->c, std::move(res), out_device, out, out_schema);
+  });
+}
+
+chq_status chq_record_to_device(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, ArrowDeviceArray* out,
+                                ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    if (in.on_device) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "record is already device resident"};
+    Batch dev = to_device(ctx->c, in);
+    check_hip(hipStreamSynchronize(ctx->c.stream), "hipStreamSynchronize");
+    export_batch(std::move(dev), ARROW_DEVICE_ROCM, out, out_schema);
+  });
+}
+
+chq_status chq_record_to_host(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, ArrowDeviceArray* out,
+                              ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    if (!in.on_device) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "record is already host resident"};
+    for (Column& c : in.cols) if (c.validity && c.null_count < 0) c.null_count = 1;
+    Batch h = to_host(ctx->c, in);
+    // resolve unknown null counts on the host copy
+    for (Column& c : h.cols) {
+      if (c.validity) {
+        int64_t nulls = 0;
+        for (int64_t i = 0; i < c.length; ++i) { int64_t b = c.offset + i; nulls += !((c.validity[b >> 3] >> (b & 7)) & 1); }
+        c.null_count = nulls;
+      }
+    }
+    export_batch(std::move(h), ARROW_DEVICE_CPU, out, out_schema);
+  });
+}
+
+chq_status chq_wrap_columns(chq_ctx* ctx, const chq_column_desc* cols, int n_cols, int64_t n_rows, int device_type,
+                            ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema");
+    if (n_cols > 0) require(cols, "column descriptors");
+    Batch b;
+    b.nrows = n_rows; b.on_device = device_type == ARROW_DEVICE_ROCM; b.device_id = ctx->c.device;
+    for (int i = 0; i < n_cols; ++i) {
+      Column c;
+      c.name = cols[i].name ? cols[i].name : ""; c.format = cols[i].format ? cols[i].format : "";
+      // validate the format through the importer's table
+      ArrowSchema tmp{}; tmp.format = c.format.c_str();
+      {
+        ArrowSchema parent{}; ArrowSchema* kids[1] = {&tmp}; parent.format = "+s"; parent.n_children = 1; parent.children = kids;
+        ArrowArray ka{}; ArrowArray* akids[1] = {&ka}; ArrowDeviceArray da{}; da.array.n_children = 1; da.array.children = akids;
+        da.device_type = ARROW_DEVICE_CPU;
+        Batch probe = import_batch(&da, &parent);
+        c.type = probe.cols[0].type; c.width = probe.cols[0].width;
+      }
+      c.nullable = cols[i].nullable != 0; c.length = n_rows; c.null_count = cols[i].validity ? cols[i].null_count : 0; c.offset = cols[i].offset;
+      c.validity = (const uint8_t*)cols[i].validity; c.values = (const uint8_t*)cols[i].values; c.data = (const uint8_t*)cols[i].data;
+      b.cols.push_back(std::move(c));
+    }
+    export_batch(std::move(b), device_type, out, out_schema);
+  });
+}
+
+}  // extern "C"

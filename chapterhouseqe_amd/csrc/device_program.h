@@ -1,0 +1,146 @@
+// device_program.h -- the flat accumulator-machine program the host lowers a sqlparser Expr into, and
+// the kernel parameter blocks.  Shared by host (plan.cpp / engine.cpp) and device (kernels.hip).
+//
+// The reference walks the Expr tree once per batch and calls one arrow-rs kernel per node, each
+// materialising a full temporary array (RU/compute_value.rs:66-218).  Here the whole tree becomes one
+// short program that every wavefront interprets over its 64 x R rows held in registers, so an
+// expression costs one pass over its input columns and no temporaries in HBM.
+#pragma once
+#include <stdint.h>
+
+namespace chq {
+
+typedef unsigned long long u64;   // what HIP's 64-bit atomics take
+
+// Arrow types in scope (the ones RU/compute_value.rs:350-431 can coerce, plus opaque pass-through).
+enum DType : uint8_t {
+  T_BOOL = 0, T_I8, T_I16, T_I32, T_I64, T_U8, T_U16, T_U32, T_U64, T_F16, T_F32, T_F64, T_UTF8,
+  T_FIXED_OPAQUE,  // fixed-width type that is only copied (date/time/timestamp/decimal/...)
+  T_NTYPES
+};
+
+enum Op : uint8_t {
+  OP_LOAD = 0,   // acc = src
+  OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_REM,             // acc = acc (op) src   [REV: src (op) acc]
+  OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE,           // acc:bool = acc (cmp) src
+  OP_AND, OP_OR,                                      // acc:bool = acc (and/or) src, non-Kleene
+  OP_CAST,       // acc: src_type -> type
+  OP_TOBOOL,     // acc:bool = acc != 0                (compute::cast(x, Boolean))
+  OP_SPILL,      // temp[src_idx] = acc (type = acc type)
+  OP_STRCMP,     // acc:bool = utf8 column refs[src_idx] (cmp imm>>56) const string #(imm & 0xffff) or column
+  OP_STORE,      // projection: out[src_idx] = acc
+  OP_NOPS
+};
+
+enum SrcKind : uint8_t { SRC_NONE = 0, SRC_COL, SRC_CONST, SRC_TEMP };
+enum InstrFlags : uint8_t { IF_REV = 1, IF_STR_RHS_COL = 2 };
+
+struct Instr {           // 16 bytes
+  uint8_t op;
+  uint8_t type;          // type the operation is carried out in / acc type after LOAD/CAST
+  uint8_t src_kind;
+  uint8_t src_type;      // stored type of the operand; converted to `type` while fetching
+  uint16_t src_idx;      // column-ref index, temp slot, output index
+  uint8_t flags;
+  uint8_t ref_order;     // position in the reference's evaluation order (error priority)
+  uint64_t imm;          // constant bits for SRC_CONST
+};
+
+struct ColRef {          // one input column referenced by the program (48 bytes)
+  const void* values;    // fixed: values at row 0; bool: bitmap; utf8: int32 offsets at row 0
+  const void* validity;  // bitmap or null
+  const void* data;      // utf8 bytes
+  int64_t validity_bit_offset;
+  int64_t bool_bit_offset;
+  uint8_t type;
+  uint8_t pad[7];
+};
+
+struct ConstStr { const uint8_t* bytes; int64_t len; };  // device-resident scalar string
+
+// fixed-width column compaction descriptor
+struct OutCol {
+  const void* in;        // values at row 0
+  void* out;
+  uint32_t width;        // 1,2,4,8,16 bytes
+  uint32_t pad;
+};
+
+// projection output descriptor
+struct ProjOut {
+  void* values;          // typed values, or bitmap for bool
+  u64* validity;    // bitmap (u64 words) or null when the expression cannot produce nulls
+  u64* null_count;  // device counter
+  uint8_t type;
+  uint8_t pad[7];
+};
+
+constexpr int MAX_INSTR = 40;
+constexpr int MAX_REFS = 12;
+constexpr int MAX_OUT = 40;
+constexpr int MAX_PROJ = 16;
+constexpr int MAX_CONST_STR = 4;
+constexpr int MAX_BOOL_TEMPS = 4;
+constexpr int MAX_NUM_TEMPS = 2;
+
+// error word, combined with atomicMin so the reference's "first error wins" order is reproduced:
+//   [63:56] position of the node in the reference's evaluation order, [55:8] row index, [7:0] code
+constexpr u64 ERR_NONE = ~0ULL;
+enum DevErr : uint32_t { DE_OVERFLOW = 1, DE_DIV_ZERO = 2 };
+
+struct ProgramBlock {
+  int32_t n_instr;
+  int32_t n_refs;
+  Instr prog[MAX_INSTR];
+  ColRef refs[MAX_REFS];
+  ConstStr strs[MAX_CONST_STR];
+};
+
+struct FilterParams {
+  int64_t nrows;          // rows the mask covers
+  u64* status;       // per tile: flag(2) | value(62); zeroed before launch
+  uint32_t* ticket;       // zeroed before launch
+  u64* total;        // out: number of selected rows
+  u64* err;          // ERR_NONE before launch
+  u64* sel_mask;     // optional: selection bitmap (one u64 per 64 rows), for follow-up kernels
+  u64* grp_base;     // optional: output row index of each 64-row group's first selected row
+  int32_t n_out;
+  int32_t pad;
+  ProgramBlock pb;
+  OutCol outs[MAX_OUT];
+};
+
+struct ProjectParams {
+  int64_t nrows;
+  u64* err;
+  int32_t n_proj;
+  int32_t pad;
+  ProgramBlock pb;
+  ProjOut outs[MAX_PROJ];
+};
+
+// follow-up kernels driven by the selection bitmap + per-tile inclusive prefixes left in `status`
+struct BitCompactParams {   // bool values / validity bitmaps
+  int64_t nrows;
+  const u64* sel_mask;
+  const u64* grp_base;
+  const void* in_bits; int64_t in_bit_offset;
+  uint32_t* out_bits;       // zero-initialised; bit k = k-th selected row
+  u64* zero_count;     // optional: counts selected rows whose bit is 0 (null count)
+};
+
+struct Utf8Params {
+  int64_t nrows;
+  const u64* sel_mask;
+  const u64* grp_base;   // output row index per 64-row group (from the main kernel)
+  const int32_t* in_offsets;  // at row 0
+  const uint8_t* in_data;
+  int32_t* out_offsets;       // [rows_out + 1]
+  uint8_t* out_data;
+  u64* byte_status;      // look-back state for the byte scan; zeroed before launch
+  uint32_t* ticket;
+  u64* total_bytes;
+  int64_t rows_out;           // number of selected rows (known on the host by now)
+};
+
+}  // namespace chq

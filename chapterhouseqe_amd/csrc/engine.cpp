@@ -1,0 +1,845 @@
+// engine.cpp -- context, HBM pool, Arrow C Data import/export, and the record-level operations that
+// drive the kernels.  Reference map: filter_record = RU/filter_record.rs:21-39, project_record =
+// RU/record_projection.rs:16-76, compute_value = RU/compute_value.rs:57-344 (RU = src/handlers/
+// operator_handler/operators/record_utils of the reference).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+namespace chq {
+
+void check_hip(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    int code = (e == hipErrorOutOfMemory) ? CHQ_ERR_OUT_OF_MEMORY : CHQ_ERR_DEVICE;
+    throw ChqError{code, std::string(what) + ": " + hipGetErrorString(e)};
+  }
+}
+
+// =================================================================================================
+// memory
+// =================================================================================================
+DevicePool& DevicePool::instance() {
+  static DevicePool* pool = new DevicePool();   // intentionally leaked: must outlive late Arrow releases
+  return *pool;
+}
+static size_t size_class(size_t bytes) {
+  if (bytes < 256) return 256;
+  if (bytes <= (1u << 20)) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+  const size_t g = 2u << 20;
+  return (bytes + g - 1) / g * g;
+}
+void* DevicePool::alloc(size_t bytes, int device) {
+  const size_t cap = size_class(bytes);
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (size_t i = 0; i < free_.size(); ++i) {
+      if (free_[i].cap == cap && free_[i].device == device) {
+        Block b = free_[i];
+        free_[i] = free_.back(); free_.pop_back();
+        live_.push_back(b);
+        return b.p;
+      }
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cap);
+  if (e == hipErrorOutOfMemory) { trim(); e = hipMalloc(&p, cap); }
+  check_hip(e, "hipMalloc");
+  std::lock_guard<std::mutex> lk(mu_);
+  live_.push_back(Block{p, cap, device});
+  return p;
+}
+void DevicePool::free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(mu_);
+  for (size_t i = 0; i < live_.size(); ++i) {
+    if (live_[i].p == p) { free_.push_back(live_[i]); live_[i] = live_.back(); live_.pop_back(); return; }
+  }
+}
+void DevicePool::trim() {
+  std::vector<Block> f;
+  { std::lock_guard<std::mutex> lk(mu_); f.swap(free_); }
+  for (auto& b : f) (void)hipFree(b.p);
+}
+
+Buffer::~Buffer() {
+  if (!ptr) return;
+  if (device) DevicePool::instance().free(ptr); else ::free(ptr);
+}
+BufferPtr make_device_buffer(size_t bytes, int device) {
+  auto b = std::make_shared<Buffer>();
+  b->ptr = DevicePool::instance().alloc(bytes ? bytes : 1, device);
+  b->bytes = bytes; b->device = true;
+  return b;
+}
+BufferPtr make_host_buffer(size_t bytes) {
+  auto b = std::make_shared<Buffer>();
+  void* p = nullptr;
+  if (posix_memalign(&p, 64, ((bytes ? bytes : 1) + 63) / 64 * 64) != 0) throw ChqError{CHQ_ERR_OUT_OF_MEMORY, "host allocation failed"};
+  b->ptr = p; b->bytes = bytes; b->device = false;
+  return b;
+}
+
+Context::~Context() {
+  if (pinned) (void)hipHostFree(pinned);
+  if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+// =================================================================================================
+// Arrow C Data Interface
+// =================================================================================================
+const void* Column::values0() const {
+  if (type == T_BOOL) return values;
+  if (type == T_UTF8) return values ? values + 4 * offset : nullptr;
+  return values ? values + (int64_t)width * offset : nullptr;
+}
+
+static void parse_format(const char* f, DType* t, int* width) {
+  *width = 0;
+  std::string s(f ? f : "");
+  if (s == "b") { *t = T_BOOL; return; }
+  if (s == "c") { *t = T_I8; *width = 1; return; }
+  if (s == "C") { *t = T_U8; *width = 1; return; }
+  if (s == "s") { *t = T_I16; *width = 2; return; }
+  if (s == "S") { *t = T_U16; *width = 2; return; }
+  if (s == "i") { *t = T_I32; *width = 4; return; }
+  if (s == "I") { *t = T_U32; *width = 4; return; }
+  if (s == "l") { *t = T_I64; *width = 8; return; }
+  if (s == "L") { *t = T_U64; *width = 8; return; }
+  if (s == "e") { *t = T_F16; *width = 2; return; }
+  if (s == "f") { *t = T_F32; *width = 4; return; }
+  if (s == "g") { *t = T_F64; *width = 8; return; }
+  if (s == "u") { *t = T_UTF8; return; }
+  *t = T_FIXED_OPAQUE;
+  if (s == "tdD" || s == "tts" || s == "ttm") { *width = 4; return; }
+  if (s == "tdm" || s == "ttu" || s == "ttn" || s.rfind("ts", 0) == 0 || s.rfind("tD", 0) == 0) { *width = 8; return; }
+  if (s.rfind("d:", 0) == 0) {   // decimal128 unless a bit width says otherwise
+    int commas = (int)std::count(s.begin(), s.end(), ',');
+    if (commas == 1) { *width = 16; return; }
+    if (commas == 2) { int bw = atoi(s.substr(s.rfind(',') + 1).c_str()); if (bw == 32) { *width = 4; return; } if (bw == 64) { *width = 8; return; } if (bw == 128) { *width = 16; return; } }
+  }
+  if (s.rfind("w:", 0) == 0) { int w = atoi(s.c_str() + 2); if (w == 1 || w == 2 || w == 4 || w == 8 || w == 16) { *width = w; return; } }
+  throw ChqError{CHQ_ERR_NOT_SUPPORTED, "Arrow type with format '" + s + "' is outside this build's scope"};
+}
+
+Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema) {
+  if (!rec || !schema || !schema->format) throw ChqError{CHQ_ERR_INVALID_HANDLE, "null record batch"};
+  if (std::string(schema->format) != "+s") throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "record batch must be a struct array"};
+  const ArrowArray& a = rec->array;
+  if (a.offset != 0) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "sliced struct arrays are not supported; slice the children"};
+  if (a.n_children != schema->n_children) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "schema / array children mismatch"};
+  Batch b;
+  b.nrows = a.length;
+  b.device_id = (int)rec->device_id;
+  switch (rec->device_type) {
+    case ARROW_DEVICE_CPU: case ARROW_DEVICE_ROCM_HOST: case ARROW_DEVICE_CUDA_HOST: b.on_device = false; break;
+    case ARROW_DEVICE_ROCM: b.on_device = true; break;
+    default: throw ChqError{CHQ_ERR_NOT_SUPPORTED, "unsupported Arrow device type"};
+  }
+  if (b.on_device && rec->sync_event) check_hip(hipEventSynchronize(*(hipEvent_t*)rec->sync_event), "hipEventSynchronize(sync_event)");
+  for (int64_t i = 0; i < a.n_children; ++i) {
+    const ArrowArray* ca = a.children[i];
+    const ArrowSchema* cs = schema->children[i];
+    Column c;
+    c.name = cs->name ? cs->name : "";
+    c.format = cs->format ? cs->format : "";
+    parse_format(cs->format, &c.type, &c.width);
+    c.nullable = (cs->flags & ARROW_FLAG_NULLABLE) != 0;
+    if (ca->length < b.nrows) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "column shorter than the record batch"};
+    c.length = b.nrows;
+    c.offset = ca->offset;
+    c.validity = ca->n_buffers > 0 ? (const uint8_t*)ca->buffers[0] : nullptr;
+    c.values = ca->n_buffers > 1 ? (const uint8_t*)ca->buffers[1] : nullptr;
+    c.data = ca->n_buffers > 2 ? (const uint8_t*)ca->buffers[2] : nullptr;
+    c.null_count = ca->null_count;   // -1 = unknown, resolved when staged
+    if (!c.validity) c.null_count = 0;
+    b.cols.push_back(std::move(c));
+  }
+  return b;
+}
+
+namespace {
+struct ArrayHolder {
+  std::vector<const void*> buffers;
+  std::vector<ArrowArray*> child_ptrs;
+  std::vector<ArrowArray> children;
+  std::vector<BufferPtr> owned;
+};
+struct SchemaHolder {
+  std::string format, name;
+  std::vector<ArrowSchema*> child_ptrs;
+  std::vector<ArrowSchema> children;
+};
+void release_array(ArrowArray* a) {
+  if (!a || !a->release) return;
+  auto* h = (ArrayHolder*)a->private_data;
+  if (h) { for (auto& c : h->children) if (c.release) c.release(&c); delete h; }
+  a->release = nullptr; a->private_data = nullptr;
+}
+void release_schema(ArrowSchema* s) {
+  if (!s || !s->release) return;
+  auto* h = (SchemaHolder*)s->private_data;
+  if (h) { for (auto& c : h->children) if (c.release) c.release(&c); delete h; }
+  s->release = nullptr; s->private_data = nullptr;
+}
+void fill_column_array(Column&& c, ArrowArray* out) {
+  auto* h = new ArrayHolder();
+  h->owned = std::move(c.owned);
+  const bool keep_validity = c.validity && c.null_count != 0;
+  h->buffers.push_back(keep_validity ? c.validity : nullptr);
+  h->buffers.push_back(c.values);
+  if (c.type == T_UTF8) h->buffers.push_back(c.data);
+  memset(out, 0, sizeof(*out));
+  out->length = c.length; out->null_count = keep_validity ? c.null_count : 0; out->offset = c.offset;
+  out->n_buffers = (int64_t)h->buffers.size(); out->buffers = h->buffers.data();
+  out->release = release_array; out->private_data = h;
+}
+void fill_column_schema(const Column& c, ArrowSchema* out) {
+  auto* h = new SchemaHolder();
+  h->format = c.format; h->name = c.name;
+  memset(out, 0, sizeof(*out));
+  out->format = h->format.c_str(); out->name = h->name.c_str();
+  out->flags = c.nullable ? ARROW_FLAG_NULLABLE : 0;
+  out->release = release_schema; out->private_data = h;
+}
+}  // namespace
+
+void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  auto* ah = new ArrayHolder();
+  auto* sh = new SchemaHolder();
+  const size_t n = b.cols.size();
+  ah->children.resize(n); sh->children.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    fill_column_schema(b.cols[i], &sh->children[i]);
+    fill_column_array(std::move(b.cols[i]), &ah->children[i]);
+  }
+  for (size_t i = 0; i < n; ++i) { ah->child_ptrs.push_back(&ah->children[i]); sh->child_ptrs.push_back(&sh->children[i]); }
+  ah->buffers.push_back(nullptr);
+  memset(out, 0, sizeof(*out));
+  out->array.length = b.nrows; out->array.null_count = 0; out->array.offset = 0;
+  out->array.n_buffers = 1; out->array.buffers = ah->buffers.data();
+  out->array.n_children = (int64_t)n; out->array.children = ah->child_ptrs.data();
+  out->array.release = release_array; out->array.private_data = ah;
+  out->device_id = device_type == ARROW_DEVICE_ROCM ? b.device_id : -1;
+  out->device_type = device_type; out->sync_event = nullptr;
+  sh->format = "+s"; sh->name = "";
+  memset(out_schema, 0, sizeof(*out_schema));
+  out_schema->format = sh->format.c_str(); out_schema->name = sh->name.c_str();
+  out_schema->n_children = (int64_t)n; out_schema->children = sh->child_ptrs.data();
+  out_schema->release = release_schema; out_schema->private_data = sh;
+}
+
+void export_single_column(Column&& c, bool on_device, int device_id, ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  fill_column_schema(c, out_schema);
+  memset(out, 0, sizeof(*out));
+  fill_column_array(std::move(c), &out->array);
+  out->device_id = on_device ? device_id : -1;
+  out->device_type = on_device ? ARROW_DEVICE_ROCM : ARROW_DEVICE_CPU;
+}
+
+// =================================================================================================
+// host <-> device staging
+// =================================================================================================
+namespace {
+// byte range of a bitmap covering bits [offset, offset+len), keeping the sub-byte phase
+struct BitRange { int64_t first_byte, nbytes; };
+BitRange bit_range(int64_t offset, int64_t len) {
+  int64_t fb = offset >> 3, lb = (offset + len + 7) >> 3;
+  return {fb, lb - fb};
+}
+enum class Dir { H2D, D2H, D2D };
+BufferPtr copy_bytes(Context& ctx, const uint8_t* src, int64_t nbytes, Dir dir, size_t pad = 16) {
+  BufferPtr out = dir == Dir::D2H ? make_host_buffer((size_t)nbytes + pad) : make_device_buffer((size_t)nbytes + pad, ctx.device);
+  if (nbytes > 0) {
+    hipMemcpyKind k = dir == Dir::H2D ? hipMemcpyHostToDevice : (dir == Dir::D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    check_hip(hipMemcpyAsync(out->ptr, src, (size_t)nbytes, k, ctx.stream), "hipMemcpyAsync");
+  }
+  return out;
+}
+
+// Copy one column across (or within) memory spaces; the copy keeps `offset & 7` so that validity,
+// boolean values and value buffers share one Arrow offset.
+Column copy_column(Context& ctx, const Column& c, Dir dir) {
+  Column o;
+  o.name = c.name; o.format = c.format; o.type = c.type; o.width = c.width; o.nullable = c.nullable;
+  o.length = c.length; o.null_count = c.null_count;
+  const int64_t phase = c.offset & 7, base = c.offset - phase, n = c.length;
+  o.offset = phase;
+  if (c.validity && c.null_count != 0) {
+    BitRange r = bit_range(c.offset, n);
+    auto vb = copy_bytes(ctx, c.validity + r.first_byte, r.nbytes, dir);
+    o.validity = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+  }
+  if (c.type == T_BOOL) {
+    BitRange r = bit_range(c.offset, n);
+    auto b = copy_bytes(ctx, c.values + r.first_byte, r.nbytes, dir);
+    o.values = (const uint8_t*)b->ptr; o.owned.push_back(b);
+  } else if (c.type == T_UTF8) {
+    // offsets [base, offset+n]; data bytes [off[offset], off[offset+n]) -- need the two end offsets on the host
+    int32_t ends[2] = {0, 0};
+    if (c.values) {
+      if (dir == Dir::H2D) { const int32_t* offs = (const int32_t*)c.values; ends[0] = offs[c.offset]; ends[1] = offs[c.offset + n]; }
+      else {
+        check_hip(hipMemcpyAsync(&ends[0], c.values + 4 * c.offset, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
+        check_hip(hipMemcpyAsync(&ends[1], c.values + 4 * (c.offset + n), 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
+        check_hip(hipStreamSynchronize(ctx.stream), "sync");
+      }
+    }
+    auto ob = c.values ? copy_bytes(ctx, c.values + 4 * base, 4 * (n + phase + 1), dir) : copy_bytes(ctx, nullptr, 0, dir);
+    if (!c.values) {   // empty array without an offsets buffer: synthesise [0]
+      int32_t zero[9] = {0};
+      if (dir == Dir::D2H) memcpy(ob->ptr, zero, sizeof zero); else check_hip(hipMemcpy(ob->ptr, zero, 16, hipMemcpyHostToDevice), "memcpy");
+    }
+    o.values = (const uint8_t*)ob->ptr; o.owned.push_back(ob);
+    const int64_t nb = (int64_t)ends[1] - ends[0];
+    auto db = copy_bytes(ctx, c.data ? c.data + ends[0] : nullptr, c.data ? nb : 0, dir);
+    o.data = (const uint8_t*)db->ptr - ends[0];   // offsets stay absolute
+    o.owned.push_back(db);
+  } else {
+    auto b = copy_bytes(ctx, c.values ? c.values + (int64_t)c.width * base : nullptr, c.values ? (int64_t)c.width * (n + phase) : 0, dir);
+    o.values = (const uint8_t*)b->ptr; o.owned.push_back(b);
+  }
+  return o;
+}
+
+int64_t count_nulls_host(const uint8_t* validity, int64_t offset, int64_t n) {
+  int64_t nulls = 0;
+  for (int64_t i = 0; i < n; ++i) { int64_t b = offset + i; nulls += !((validity[b >> 3] >> (b & 7)) & 1); }
+  return nulls;
+}
+}  // namespace
+
+Batch to_device(Context& ctx, const Batch& b) {
+  Batch o;
+  o.nrows = b.nrows; o.on_device = true; o.device_id = ctx.device;
+  for (const Column& c : b.cols) {
+    Column cc = c;
+    if (!b.on_device) {
+      if (cc.validity && cc.null_count < 0) cc.null_count = count_nulls_host(cc.validity, cc.offset, cc.length);
+      o.cols.push_back(copy_column(ctx, cc, Dir::H2D));
+    } else {
+      if (cc.validity && cc.null_count < 0) cc.null_count = 1;   // unknown: assume nulls may be present
+      o.cols.push_back(cc);   // view, nothing owned
+    }
+  }
+  return o;
+}
+
+Batch to_host(Context& ctx, const Batch& b) {
+  Batch o;
+  o.nrows = b.nrows; o.on_device = false; o.device_id = -1;
+  for (const Column& c : b.cols) o.cols.push_back(b.on_device ? copy_column(ctx, c, Dir::D2H) : c);
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  return o;
+}
+
+std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* aliases) {
+  std::vector<PlanColumn> out;
+  for (size_t i = 0; i < b.cols.size(); ++i) {
+    PlanColumn p;
+    p.name = b.cols[i].name; p.type = b.cols[i].type;
+    p.has_nulls = b.cols[i].validity && b.cols[i].null_count != 0;
+    // without an explicit table_aliases argument every column has an (empty) alias list
+    p.alias_entry_present = aliases ? (int)i < aliases->n_columns : true;
+    if (aliases && (int)i < aliases->n_columns)
+      for (int k = 0; k < aliases->columns[i].n; ++k) p.aliases.push_back(aliases->columns[i].aliases[k]);
+    out.push_back(std::move(p));
+  }
+  return out;
+}
+
+// =================================================================================================
+// kernel drivers
+// =================================================================================================
+namespace {
+
+constexpr int64_t kTileRows[3] = {1024 * 16, 256 * 8, 256 * 8};
+
+struct Scratch {   // layout of ctx.small (device) and ctx.pinned (host mirror)
+  uint32_t ticket; uint32_t pad0;
+  unsigned long long total;
+  unsigned long long err;
+  unsigned long long total_bytes;
+  uint32_t ticket2; uint32_t pad1;
+  unsigned long long counters[24];
+};
+
+void ensure_scratch(Context& ctx, int64_t ntiles) {
+  const size_t need = (size_t)(ntiles + 64) * 8;
+  if (!ctx.status || ctx.status->bytes < need) ctx.status = make_device_buffer(need, ctx.device);
+  if (!ctx.small) ctx.small = make_device_buffer(sizeof(Scratch), ctx.device);
+  if (!ctx.pinned) { check_hip(hipHostMalloc(&ctx.pinned, sizeof(Scratch), hipHostMallocDefault), "hipHostMalloc"); ctx.pinned_bytes = sizeof(Scratch); }
+}
+Scratch* dev_scratch(Context& ctx) { return (Scratch*)ctx.small->ptr; }
+
+void fill_refs(ProgramBlock& pb, const Lowered& lw, const Batch& rec, const std::vector<BufferPtr>& str_bufs) {
+  pb.n_instr = (int32_t)lw.prog.size();
+  pb.n_refs = (int32_t)lw.refs.size();
+  for (size_t i = 0; i < lw.prog.size(); ++i) pb.prog[i] = lw.prog[i];
+  for (size_t i = 0; i < lw.refs.size(); ++i) {
+    const Column& c = rec.cols[lw.refs[i]];
+    ColRef r{};
+    r.values = c.values0();
+    r.validity = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+    r.data = c.data;
+    r.validity_bit_offset = c.offset;
+    r.bool_bit_offset = c.offset;
+    r.type = c.type;
+    pb.refs[i] = r;
+  }
+  for (size_t i = 0; i < lw.strs.size(); ++i) { pb.strs[i].bytes = (const uint8_t*)str_bufs[i]->ptr; pb.strs[i].len = (int64_t)lw.strs[i].size(); }
+}
+
+std::vector<BufferPtr> upload_strings(Context& ctx, const Lowered& lw) {
+  std::vector<BufferPtr> out;
+  for (const auto& s : lw.strs) {
+    auto b = make_device_buffer(s.size() + 8, ctx.device);
+    if (!s.empty()) check_hip(hipMemcpyAsync(b->ptr, s.data(), s.size(), hipMemcpyHostToDevice, ctx.stream), "upload string literal");
+    out.push_back(b);
+  }
+  // literals live on the host stack of the caller: make the copies land before returning to it
+  if (!out.empty()) check_hip(hipStreamSynchronize(ctx.stream), "sync");
+  return out;
+}
+
+[[noreturn]] void throw_device_error(unsigned long long err) {
+  const int code = (int)(err & 0xff);
+  const long long row = (long long)((err >> 8) & ((1ULL << 48) - 1));
+  if (code == DE_DIV_ZERO) throw ChqError{CHQ_ERR_ARROW_DIVIDE_BY_ZERO, "Divide by zero error (row " + std::to_string(row) + ")"};
+  throw ChqError{CHQ_ERR_ARROW_ARITHMETIC_OVERFLOW, "Overflow happened on row " + std::to_string(row)};
+}
+
+int pick_tile_kind(const Context& ctx, const Lowered& lw, int64_t rows) {
+  if (lw.wide || lw.num_temps > 0) return 2;
+  if (ctx.opt_tile_kind >= 0) return (int)ctx.opt_tile_kind;
+  return rows >= (1 << 18) ? 0 : 1;
+}
+
+Column empty_like(const Column& c) {
+  Column o;
+  o.name = c.name; o.format = c.format; o.type = c.type; o.width = c.width; o.nullable = c.nullable;
+  return o;
+}
+
+}  // namespace
+
+// =================================================================================================
+// filter_record
+// =================================================================================================
+Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr) {
+  const int64_t nrows = rec.nrows;
+  TypedExpr te = type_expr(expr, pcols, nrows, ctx.opt_enable_minus);
+  const Node& root = te.at(te.root);
+  if (root.type != T_BOOL)   // RU/filter_record.rs:27-35
+    throw ChqError{CHQ_ERR_CAST_TO_BOOLEAN_ARRAY_FAILED, std::string("cast to boolean array failed for array type: ") + dtype_name(root.type)};
+  // A literal-only predicate is a length-1 mask: arrow filters just the first row (and rejects a mask
+  // longer than the columns) -- reproduced, not "fixed" (SURVEY.md section 8 a8).
+  const int64_t mask_len = root.len1 ? 1 : nrows;
+  if (mask_len > nrows && !rec.cols.empty())
+    throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "Filter predicate of length " + std::to_string(mask_len) +
+                                                       " is larger than target array of length " + std::to_string(nrows)};
+  Lowered lw;
+  lower_expr(te, te.root, pcols, lw);
+
+  Batch out;
+  out.on_device = true; out.device_id = ctx.device;
+  ctx.stats = chq_call_stats{};
+  ctx.stats.rows_in = nrows;
+  for (const Column& c : rec.cols) out.cols.push_back(empty_like(c));
+  if (mask_len == 0) {   // empty in, empty out (schema preserved)
+    for (size_t i = 0; i < rec.cols.size(); ++i) {
+      Column& o = out.cols[i];
+      auto vb = make_device_buffer(16, ctx.device);
+      check_hip(hipMemsetAsync(vb->ptr, 0, 16, ctx.stream), "memset");
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+      if (o.type == T_UTF8) { auto db = make_device_buffer(16, ctx.device); o.data = (const uint8_t*)db->ptr; o.owned.push_back(db); }
+    }
+    check_hip(hipStreamSynchronize(ctx.stream), "sync");
+    out.nrows = 0;
+    return out;
+  }
+
+  const int tile_kind = pick_tile_kind(ctx, lw, mask_len);
+  const int64_t tile_rows = kTileRows[tile_kind];
+  const int64_t ntiles = (mask_len + tile_rows - 1) / tile_rows;
+  ensure_scratch(ctx, ntiles);
+  Scratch* ds = dev_scratch(ctx);
+  auto str_bufs = upload_strings(ctx, lw);
+
+  // classify columns
+  std::vector<int> fixed_cols, bool_cols, utf8_cols, nullable_cols;
+  for (size_t i = 0; i < rec.cols.size(); ++i) {
+    const Column& c = rec.cols[i];
+    if (c.type == T_BOOL) bool_cols.push_back((int)i);
+    else if (c.type == T_UTF8) utf8_cols.push_back((int)i);
+    else fixed_cols.push_back((int)i);
+    if (c.validity && c.null_count != 0) nullable_cols.push_back((int)i);
+  }
+  const bool need_followup = !bool_cols.empty() || !utf8_cols.empty() || !nullable_cols.empty() || (int)fixed_cols.size() > MAX_OUT;
+  const int64_t ngroups = (mask_len + 63) / 64;
+  BufferPtr sel_mask, grp_base;
+  if (need_followup) {
+    sel_mask = make_device_buffer((size_t)(ngroups + 2) * 8, ctx.device);
+    grp_base = make_device_buffer((size_t)(ngroups + 2) * 8, ctx.device);
+  }
+
+  // output buffers for fixed-width columns: capacity = mask_len rows
+  for (int ci : fixed_cols) {
+    Column& o = out.cols[ci];
+    auto vb = make_device_buffer((size_t)mask_len * o.width + 16, ctx.device);
+    o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    ctx.stats.bytes_read_alg += mask_len * o.width;
+  }
+  // predicate inputs that are not output columns cannot occur for filter_record (SELECT * semantics):
+  // every referenced column is also copied, so it is counted once above.
+
+  const int grid_cap = tile_kind == 0 ? ctx.num_cus : ctx.num_cus * 4;
+  const int grid = (int)std::min<int64_t>(ntiles, grid_cap);
+  size_t next_fixed = 0;
+  bool first = true;
+  do {
+    FilterParams p{};
+    p.nrows = mask_len;
+    p.status = (u64*)ctx.status->ptr;
+    p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
+    p.sel_mask = (first && need_followup) ? (u64*)sel_mask->ptr : nullptr;
+    p.grp_base = (first && need_followup) ? (u64*)grp_base->ptr : nullptr;
+    if (first) fill_refs(p.pb, lw, rec, str_bufs);
+    else {   // later passes re-read the selection bitmap as a Boolean column
+      p.pb.n_instr = 1; p.pb.n_refs = 1;
+      Instr in{}; in.op = OP_LOAD; in.type = T_BOOL; in.src_kind = SRC_COL; in.src_type = T_BOOL; in.src_idx = 0;
+      p.pb.prog[0] = in;
+      ColRef r{}; r.values = sel_mask->ptr; r.type = T_BOOL; p.pb.refs[0] = r;
+    }
+    int n = 0;
+    while (next_fixed < fixed_cols.size() && n < MAX_OUT) {
+      const int ci = fixed_cols[next_fixed++];
+      p.outs[n].in = rec.cols[ci].values0(); p.outs[n].out = (void*)out.cols[ci].values; p.outs[n].width = (uint32_t)rec.cols[ci].width;
+      ++n;
+    }
+    p.n_out = n;
+    check_hip(hipMemsetAsync(ctx.status->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset status");
+    check_hip(hipMemsetAsync(ds, 0, 16, ctx.stream), "memset scratch");
+    if (first) check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
+    const int kind = first ? tile_kind : (tile_kind == 2 ? 1 : tile_kind);
+    check_hip(launch_filter(p, kind, grid, ctx.stream), "launch filter_fused_kernel");
+    ++ctx.stats.launches;
+    first = false;
+  } while (next_fixed < fixed_cols.size());
+
+  Scratch* hs = (Scratch*)ctx.pinned;
+  check_hip(hipMemcpyAsync(hs, ds, 32, hipMemcpyDeviceToHost, ctx.stream), "read back");
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  if (hs->err != ERR_NONE) throw_device_error(hs->err);
+  const int64_t total = (int64_t)hs->total;
+  out.nrows = total;
+  ctx.stats.rows_out = total; ctx.stats.tiles = ntiles;
+  for (int ci : fixed_cols) { out.cols[ci].length = total; ctx.stats.bytes_written_alg += total * out.cols[ci].width; }
+
+  if (need_followup) {
+    const int fgrid = (int)std::min<int64_t>((ngroups + 31) / 32, (int64_t)ctx.num_cus * 8);
+    // ---- Boolean value bitmaps and validity bitmaps -------------------------------------------------
+    const size_t words = (size_t)(total + 31) / 32 + 2;
+    check_hip(hipMemsetAsync(&ds->counters[0], 0, sizeof(ds->counters), ctx.stream), "memset counters");
+    if (nullable_cols.size() > 24) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 24 nullable columns in one batch"};
+    auto bit_compact = [&](const uint8_t* in_bits, int64_t bit_off, u64* zero_counter) {
+      auto ob = make_device_buffer(words * 4 + 8, ctx.device);
+      check_hip(hipMemsetAsync(ob->ptr, 0, words * 4 + 8, ctx.stream), "memset bits");
+      BitCompactParams bp{};
+      bp.nrows = mask_len; bp.sel_mask = (const u64*)sel_mask->ptr; bp.grp_base = (const u64*)grp_base->ptr;
+      bp.in_bits = in_bits; bp.in_bit_offset = bit_off; bp.out_bits = (uint32_t*)ob->ptr; bp.zero_count = zero_counter;
+      check_hip(launch_bit_compact(bp, std::max(1, fgrid), ctx.stream), "launch bit_compact_kernel");
+      ++ctx.stats.launches;
+      return ob;
+    };
+    for (int ci : bool_cols) {
+      auto ob = bit_compact(rec.cols[ci].values, rec.cols[ci].offset, nullptr);
+      out.cols[ci].values = (const uint8_t*)ob->ptr; out.cols[ci].owned.push_back(ob); out.cols[ci].length = total;
+    }
+    for (size_t k = 0; k < nullable_cols.size(); ++k) {
+      const int ci = nullable_cols[k];
+      auto ob = bit_compact(rec.cols[ci].validity, rec.cols[ci].offset, &ds->counters[k]);
+      out.cols[ci].validity = (const uint8_t*)ob->ptr; out.cols[ci].owned.push_back(ob);
+    }
+    // ---- Utf8 columns: offsets, then bytes -----------------------------------------------------------
+    std::vector<BufferPtr> byte_status(utf8_cols.size());
+    std::vector<Utf8Params> ups(utf8_cols.size());
+    if (utf8_cols.size() > 8) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 8 Utf8 columns in one batch"};
+    const int64_t utiles = (mask_len + 2047) / 2048;
+    for (size_t k = 0; k < utf8_cols.size(); ++k) {
+      const int ci = utf8_cols[k];
+      const Column& c = rec.cols[ci];
+      Column& o = out.cols[ci];
+      auto offb = make_device_buffer((size_t)(total + 2) * 4, ctx.device);
+      byte_status[k] = make_device_buffer((size_t)(utiles + 64) * 8 + 16, ctx.device);
+      check_hip(hipMemsetAsync(byte_status[k]->ptr, 0, (size_t)(utiles + 64) * 8 + 16, ctx.stream), "memset");
+      Utf8Params up{};
+      up.nrows = mask_len; up.sel_mask = (const u64*)sel_mask->ptr; up.grp_base = (const u64*)grp_base->ptr;
+      up.in_offsets = (const int32_t*)c.values0(); up.in_data = c.data;
+      up.out_offsets = (int32_t*)offb->ptr; up.out_data = nullptr;
+      up.byte_status = (u64*)byte_status[k]->ptr;
+      up.ticket = (uint32_t*)((uint8_t*)byte_status[k]->ptr + (size_t)(utiles + 64) * 8);
+      up.total_bytes = &ds->counters[16 + k];   // counters[16..23] reserved for byte totals
+      up.rows_out = total;
+      ups[k] = up;
+      check_hip(launch_utf8_offsets(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 8), ctx.stream), "launch utf8_offsets_kernel");
+      ++ctx.stats.launches;
+      o.values = (const uint8_t*)offb->ptr; o.owned.push_back(offb); o.length = total;
+    }
+    check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+    for (size_t k = 0; k < nullable_cols.size(); ++k) {
+      Column& o = out.cols[nullable_cols[k]];
+      o.null_count = (int64_t)hs->counters[k];
+      if (o.null_count == 0) o.validity = nullptr;   // arrow drops an all-valid null buffer
+    }
+    for (size_t k = 0; k < utf8_cols.size(); ++k) {
+      Column& o = out.cols[utf8_cols[k]];
+      const int64_t nb = (int64_t)hs->counters[16 + k];
+      auto db = make_device_buffer((size_t)nb + 16, ctx.device);
+      ups[k].out_data = (uint8_t*)db->ptr;
+      o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
+      if (nb > 0) {
+        check_hip(launch_utf8_copy(ups[k], (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx.num_cus * 16), ctx.stream), "launch utf8_copy_kernel");
+        ++ctx.stats.launches;
+      }
+    }
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  }
+  for (Column& o : out.cols) o.length = total;
+  return out;
+}
+
+// =================================================================================================
+// project_record / compute_value
+// =================================================================================================
+namespace {
+
+// deep copy of a column inside HBM (the reference Arc-clones; inputs here are only borrowed)
+Column clone_device_column(Context& ctx, const Column& c) { return copy_column(ctx, c, Dir::D2D); }
+
+Column scalar_column(Context& ctx, const Scalar& s, const std::string& name) {
+  Column o;
+  o.name = name; o.type = s.type; o.length = 1; o.null_count = 0; o.nullable = false;
+  static const char* fmts[T_NTYPES] = {"b", "c", "s", "i", "l", "C", "S", "I", "L", "e", "f", "g", "u", ""};
+  o.format = fmts[s.type]; o.width = dtype_width(s.type);
+  if (s.type == T_UTF8) {
+    int32_t offs[2] = {0, (int32_t)s.str.size()};
+    auto ob = make_device_buffer(16, ctx.device), db = make_device_buffer(s.str.size() + 16, ctx.device);
+    check_hip(hipMemcpy(ob->ptr, offs, 8, hipMemcpyHostToDevice), "memcpy");
+    if (!s.str.empty()) check_hip(hipMemcpy(db->ptr, s.str.data(), s.str.size(), hipMemcpyHostToDevice), "memcpy");
+    o.values = (const uint8_t*)ob->ptr; o.data = (const uint8_t*)db->ptr; o.owned = {ob, db};
+  } else {
+    uint64_t bits = s.bits;
+    auto vb = make_device_buffer(16, ctx.device);
+    check_hip(hipMemcpy(vb->ptr, &bits, 8, hipMemcpyHostToDevice), "memcpy");
+    o.values = (const uint8_t*)vb->ptr; o.owned = {vb};
+  }
+  return o;
+}
+
+struct ProjItem {   // one computed output of a launch
+  int out_index;     // position in the output batch
+  int null_slot;     // counter slot, -1 when the expression cannot produce nulls
+};
+
+bool subtree_can_null(const TypedExpr& t, int ni, const std::vector<PlanColumn>& cols) {
+  const Node& n = t.at(ni);
+  if (n.kind == Node::COL) return cols[n.col].has_nulls;
+  bool r = false;
+  if (n.l >= 0) r |= subtree_can_null(t, n.l, cols);
+  if (n.r >= 0) r |= subtree_can_null(t, n.r, cols);
+  return r;
+}
+
+const char* format_of(DType t) {
+  static const char* fmts[T_NTYPES] = {"b", "c", "s", "i", "l", "C", "S", "I", "L", "e", "f", "g", "u", ""};
+  return fmts[t];
+}
+
+// Evaluate the expressions `exprs[k]` (typed trees) densely over `rec`; returns one column per expression.
+std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols,
+                                   const std::vector<const TypedExpr*>& exprs) {
+  const int64_t nrows = rec.nrows;
+  std::vector<Column> results(exprs.size());
+  for (size_t k = 0; k < exprs.size(); ++k) {
+    const Node& root = exprs[k]->at(exprs[k]->root);
+    Column& o = results[k];
+    o.type = root.type; o.format = format_of(root.type); o.width = dtype_width(root.type); o.length = nrows;
+    if (root.type == T_UTF8 || root.type == T_FIXED_OPAQUE || root.type == T_F16)
+      throw ChqError{CHQ_ERR_NOT_SUPPORTED, std::string("expression result of type ") + dtype_name(root.type) + " is outside this build's scope"};
+  }
+  if (nrows == 0) {
+    for (Column& o : results) { auto vb = make_device_buffer(16, ctx.device); o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb); }
+    return results;
+  }
+  ensure_scratch(ctx, 1);
+  Scratch* ds = dev_scratch(ctx);
+  Scratch* hs = (Scratch*)ctx.pinned;
+  size_t k = 0;
+  while (k < exprs.size()) {
+    // pack as many expressions as fit the program limits into one launch
+    Lowered lw;
+    std::vector<ProjItem> items;
+    int null_slots = 0;
+    size_t k0 = k;
+    for (; k < exprs.size() && (int)items.size() < MAX_PROJ; ++k) {
+      Lowered trial = lw;
+      try {
+        lower_expr(*exprs[k], exprs[k]->root, pcols, trial);
+        if ((int)trial.prog.size() + 1 > MAX_INSTR) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "program too long"};
+      } catch (const ChqError& e) {
+        if (k == k0) throw;   // does not fit even alone
+        break;
+      }
+      Instr st{}; st.op = OP_STORE; st.src_idx = (uint16_t)items.size(); st.src_kind = SRC_NONE;
+      trial.prog.push_back(st);
+      lw = std::move(trial);
+      const bool can_null = subtree_can_null(*exprs[k], exprs[k]->root, pcols);
+      if (can_null && null_slots >= 16) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "too many nullable outputs in one projection"};
+      items.push_back(ProjItem{(int)k, can_null ? null_slots++ : -1});
+    }
+    ProjectParams p{};
+    p.nrows = nrows; p.err = &ds->err; p.n_proj = (int32_t)items.size();
+    auto str_bufs = upload_strings(ctx, lw);
+    fill_refs(p.pb, lw, rec, str_bufs);
+    for (size_t i = 0; i < items.size(); ++i) {
+      Column& o = results[items[i].out_index];
+      const size_t vbytes = o.type == T_BOOL ? (size_t)((nrows + 63) / 64) * 8 + 16 : (size_t)nrows * o.width + 16;
+      auto vb = make_device_buffer(vbytes, ctx.device);
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+      ProjOut po{};
+      po.values = vb->ptr; po.type = o.type;
+      if (items[i].null_slot >= 0) {
+        auto nb = make_device_buffer((size_t)((nrows + 63) / 64) * 8 + 16, ctx.device);
+        o.validity = (const uint8_t*)nb->ptr; o.owned.push_back(nb);
+        po.validity = (u64*)nb->ptr; po.null_count = &ds->counters[items[i].null_slot];
+      }
+      p.outs[i] = po;
+    }
+    check_hip(hipMemsetAsync(ds, 0, sizeof(Scratch), ctx.stream), "memset scratch");
+    check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
+    const int tile_kind = pick_tile_kind(ctx, lw, nrows);
+    const int64_t ntiles = (nrows + kTileRows[tile_kind] - 1) / kTileRows[tile_kind];
+    const int grid = (int)std::min<int64_t>(ntiles, tile_kind == 0 ? (int64_t)ctx.num_cus * 2 : (int64_t)ctx.num_cus * 8);
+    check_hip(launch_project(p, tile_kind, grid, ctx.stream), "launch project_kernel");
+    ++ctx.stats.launches;
+    check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+    if (hs->err != ERR_NONE) throw_device_error(hs->err);
+    for (const ProjItem& it : items) {
+      Column& o = results[it.out_index];
+      if (it.null_slot >= 0) { o.null_count = (int64_t)hs->counters[it.null_slot]; if (o.null_count == 0) o.validity = nullptr; }
+    }
+  }
+  return results;
+}
+
+// the result of one compute_value call: a passthrough column, a literal-built length-1 array, or a program
+struct Evaluated {
+  enum Kind { PASSTHROUGH, SCALAR, COMPUTED } kind;
+  int col = -1;
+  Scalar value;
+  TypedExpr typed;
+  bool is_scalar = false;
+};
+
+Evaluated classify(const Expr& e, const std::vector<PlanColumn>& pcols, int64_t nrows, bool enable_minus) {
+  Evaluated ev;
+  ev.typed = type_expr(e, pcols, nrows, enable_minus);
+  const Node& root = ev.typed.at(ev.typed.root);
+  ev.is_scalar = root.is_scalar;
+  if (root.kind == Node::COL) { ev.kind = Evaluated::PASSTHROUGH; ev.col = root.col; }
+  else if (root.len1) { ev.kind = Evaluated::SCALAR; ev.value = fold_constant(ev.typed, ev.typed.root); }
+  else ev.kind = Evaluated::COMPUTED;
+  return ev;
+}
+
+}  // namespace
+
+Column compute_value(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr, bool* is_scalar) {
+  ctx.stats = chq_call_stats{};
+  Evaluated ev = classify(expr, pcols, rec.nrows, ctx.opt_enable_minus);
+  if (is_scalar) *is_scalar = ev.is_scalar;
+  Column out;
+  switch (ev.kind) {
+    case Evaluated::PASSTHROUGH: out = clone_device_column(ctx, rec.cols[ev.col]); check_hip(hipStreamSynchronize(ctx.stream), "sync"); break;
+    case Evaluated::SCALAR: out = scalar_column(ctx, ev.value, ""); break;
+    default: { std::vector<const TypedExpr*> v{&ev.typed}; out = std::move(evaluate_dense(ctx, rec, pcols, v)[0]); } break;
+  }
+  out.nullable = out.null_count > 0;
+  return out;
+}
+
+Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec,
+                     const std::vector<PlanColumn>& pcols) {
+  ctx.stats = chq_call_stats{};
+  Batch out;
+  out.on_device = true; out.device_id = ctx.device;
+  std::vector<Evaluated> evs;            // computed items, evaluated together after the walk
+  std::vector<int> computed_slot;        // output column index of each computed item
+  size_t unnamed_idx = 0;
+  for (const chq_select_item& f : fields) {
+    switch (f.kind) {
+      case CHQ_ITEM_WILDCARD:   // RU/record_projection.rs:27-32
+        for (const Column& c : rec.cols) out.cols.push_back(clone_device_column(ctx, c));
+        break;
+      case CHQ_ITEM_QUALIFIED_WILDCARD:
+        throw ChqError{CHQ_ERR_PROJECT_NOT_IMPLEMENTED, "not implemented: SelectItem::QualifiedWildcard"};
+      case CHQ_ITEM_UNNAMED_EXPR:
+      case CHQ_ITEM_EXPR_WITH_ALIAS: {
+        if (!f.expr) throw ChqError{CHQ_ERR_INVALID_HANDLE, "select item without expression"};
+        const Expr& e = *(const Expr*)f.expr;
+        Evaluated ev = classify(e, pcols, rec.nrows, ctx.opt_enable_minus);
+        std::string name;
+        if (f.kind == CHQ_ITEM_EXPR_WITH_ALIAS) name = f.alias ? f.alias : "";
+        else if (e.kind == Expr::IDENT) name = e.text;                 // RU/record_projection.rs:41-48
+        else name = "unnamed_" + std::to_string(unnamed_idx);          // :49-53
+        if (f.kind == CHQ_ITEM_UNNAMED_EXPR) ++unnamed_idx;           // :58, counts identifiers too
+        Column col;
+        if (ev.kind == Evaluated::PASSTHROUGH) col = clone_device_column(ctx, rec.cols[ev.col]);
+        else if (ev.kind == Evaluated::SCALAR) col = scalar_column(ctx, ev.value, name);
+        else { computed_slot.push_back((int)out.cols.size()); evs.push_back(std::move(ev)); }
+        col.name = name;
+        out.cols.push_back(std::move(col));
+      } break;
+      default: throw ChqError{CHQ_ERR_INVALID_HANDLE, "unknown select item kind"};
+    }
+  }
+  if (!evs.empty()) {
+    std::vector<const TypedExpr*> ptrs;
+    for (auto& ev : evs) ptrs.push_back(&ev.typed);
+    std::vector<Column> cols = evaluate_dense(ctx, rec, pcols, ptrs);
+    for (size_t i = 0; i < cols.size(); ++i) {
+      std::string name = out.cols[computed_slot[i]].name;
+      out.cols[computed_slot[i]] = std::move(cols[i]);
+      out.cols[computed_slot[i]].name = name;
+    }
+  }
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  // Field nullability: wildcard fields keep the schema flag; computed / identifier fields use
+  // Array::is_nullable() = null_count > 0 (RU/record_projection.rs:45-47, 51-53, 62-66)
+  {
+    size_t k = 0;
+    for (const chq_select_item& f : fields) {
+      if (f.kind == CHQ_ITEM_WILDCARD) { k += rec.cols.size(); continue; }
+      out.cols[k].nullable = out.cols[k].null_count > 0;
+      ++k;
+    }
+  }
+  // RecordBatch::try_new (RU/record_projection.rs:72-73)
+  if (out.cols.empty()) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "must either specify a row count or at least one column"};
+  const int64_t len = out.cols[0].length;
+  for (const Column& c : out.cols) {
+    if (c.length != len) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "all columns in a record batch must have the same length"};
+    if (!c.nullable && c.null_count > 0)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "Column '" + c.name + "' is declared as non-nullable but contains null values"};
+  }
+  out.nrows = len;
+  return out;
+}
+
+}  // namespace chq

@@ -1,0 +1,122 @@
+// engine.hpp -- context, device memory, Arrow C Data import/export and the record-level operations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/chq.h"
+#include "device_program.h"
+#include "plan.hpp"
+
+namespace chq {
+
+// kernels.hip
+hipError_t launch_filter(const FilterParams& p, int tile_kind, int grid, hipStream_t stream);
+hipError_t launch_project(const ProjectParams& p, int tile_kind, int grid, hipStream_t stream);
+hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
+hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
+hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
+
+// ---- memory ---------------------------------------------------------------------------------------
+// Process-wide caching allocator for HBM (outlives contexts: Arrow release callbacks may run after the
+// context that produced a batch is gone).  Blocks are recycled by size class; nothing is returned to
+// HIP until trim().
+class DevicePool {
+ public:
+  static DevicePool& instance();
+  void* alloc(size_t bytes, int device);
+  void free(void* p);
+  void trim();
+ private:
+  struct Block { void* p; size_t cap; int device; };
+  std::mutex mu_;
+  std::vector<Block> free_;
+  std::vector<Block> live_;
+};
+
+// One allocation (device or host) owned by an exported batch.
+struct Buffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  bool device = false;
+  ~Buffer();
+  Buffer() = default;
+  Buffer(const Buffer&) = delete;
+  Buffer& operator=(const Buffer&) = delete;
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+BufferPtr make_device_buffer(size_t bytes, int device);
+BufferPtr make_host_buffer(size_t bytes);
+
+// ---- batches ----------------------------------------------------------------------------------------
+// A column as stored (device or host pointers), Arrow layout.
+struct Column {
+  std::string name;
+  std::string format;      // Arrow C format string
+  DType type = T_FIXED_OPAQUE;
+  int width = 0;           // bytes per value for fixed-width types
+  bool nullable = false;   // schema flag
+  int64_t length = 0;
+  int64_t null_count = 0;
+  int64_t offset = 0;      // Arrow slice offset (elements)
+  const uint8_t* validity = nullptr;
+  const uint8_t* values = nullptr;   // fixed: values buffer; bool: bitmap; utf8: int32 offsets buffer
+  const uint8_t* data = nullptr;     // utf8 bytes
+  std::vector<BufferPtr> owned;      // keeps staged / produced buffers alive
+
+  // derived views (element 0 = first logical row)
+  const void* values0() const;       // fixed: values + offset*width; utf8: offsets + offset
+  int64_t bool_bit_offset() const { return offset; }
+  int64_t validity_bit_offset() const { return offset; }
+};
+
+struct Batch {
+  int64_t nrows = 0;
+  bool on_device = false;
+  int device_id = 0;
+  std::vector<Column> cols;
+};
+
+// ---- context ------------------------------------------------------------------------------------------
+struct Context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 0;
+  std::string last_error;
+  chq_call_stats stats{};
+  // options
+  int64_t opt_tile_kind = -1;       // -1 auto
+  bool opt_enable_minus = false;
+  // reusable device scratch
+  BufferPtr status, byte_status, small;   // small: ticket(4) pad total(8) err(8) total_bytes(8) counters...
+  void* pinned = nullptr;                  // pinned host staging for small read-backs (256 B)
+  size_t pinned_bytes = 0;
+
+  ~Context();
+};
+
+void check_hip(hipError_t e, const char* what);
+
+// Arrow C Data Interface <-> Batch
+Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema);
+void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema* out_schema);
+void export_single_column(Column&& c, bool on_device, int device_id, ArrowDeviceArray* out, ArrowSchema* out_schema);
+
+Batch to_device(Context& ctx, const Batch& b);   // stage host batch into HBM (no-op view when already there)
+Batch to_host(Context& ctx, const Batch& b);
+
+// the record-level operations (throw ChqError)
+Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr);
+Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_dev,
+                     const std::vector<PlanColumn>& pcols);
+Column compute_value(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr,
+                     bool* is_scalar);
+
+std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* aliases);
+
+}  // namespace chq

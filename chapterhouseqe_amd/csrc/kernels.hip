@@ -1,0 +1,900 @@
+// kernels.hip -- hand-written gfx950 kernels for the filter / projection record path.
+//
+// What each kernel replaces in the reference (RU = src/handlers/operator_handler/operators/record_utils):
+//   filter_fused_kernel   RU/filter_record.rs:21-39  = compute_value (predicate) + arrow filter_record_batch
+//   project_kernel        RU/record_projection.rs:16-76 = one compute_value per SelectItem
+//   bit_compact_kernel    arrow-select filter of Boolean values / validity bitmaps
+//   utf8_*_kernel         arrow-select filter of Utf8 (offset rebuild + byte copy)
+//
+// Design (memory-bound path, no MFMA): one wavefront owns 64*R consecutive rows ("column chunk");
+// lane l, slot j holds row  w0 + 64*j + l, so every global load/store instruction of a wave touches
+// one contiguous 64-element run.  A comparison becomes one 64-bit ballot per slot, boolean combine is
+// scalar arithmetic on those ballots, a row's output position is  tile_base + wave_prefix +
+// popcount(earlier slots) + mbcnt(ballot).  Tile bases come from a single-pass chained scan
+// (decoupled look-back on 8-byte {flag,value} words written/read with agent-scope relaxed atomics),
+// software-pipelined so that a tile's aggregate is published one tile ahead of the point where its
+// successors need it.  Tiles are handed out by an atomic ticket, so the scan can never wait on a
+// workgroup that has not started (no co-residency assumption).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_program.h"
+
+namespace chq {
+
+
+// ------------------------------------------------------------------------------------------------
+// tile status words: bits 63..62 flag (0 invalid, 1 aggregate, 2 inclusive prefix), low 62 bits value
+// ------------------------------------------------------------------------------------------------
+#define ST_AGG (1ULL << 62)
+#define ST_INC (2ULL << 62)
+#define ST_VAL(x) ((x) & ((1ULL << 62) - 1))
+#define ST_FLAG(x) ((x) >> 62)
+
+__device__ __forceinline__ void st_store(u64* p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 st_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned lane_rank(u64 m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+// Sum the aggregates of the tiles before `tile` back to the nearest inclusive prefix (one wave).
+// `first_tile` is the first tile of the chain (its predecessor is a virtual inclusive 0).
+__device__ __forceinline__ u64 lookback_exclusive(const u64* status, int64_t tile, int64_t first_tile, int lane) {
+  u64 excl = 0;
+  int64_t look = tile - 1;
+  while (true) {
+    int64_t idx = look - lane;
+    u64 w = ST_INC;
+    if (idx >= first_tile) {
+      w = st_load(&status[idx]);
+      while (ST_FLAG(w) == 0) { __builtin_amdgcn_s_sleep(1); w = st_load(&status[idx]); }
+    }
+    u64 incm = __ballot(ST_FLAG(w) == 2);
+    if (incm) {
+      int first = __builtin_ctzll(incm);
+      excl += wave_sum((lane <= first) ? ST_VAL(w) : 0ULL);
+      break;
+    }
+    excl += wave_sum(ST_VAL(w));
+    look -= 64;
+  }
+  return excl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 active_mask(int64_t start, int64_t nrows) {
+  int64_t rem = nrows - start;
+  return rem >= 64 ? ~0ULL : (rem <= 0 ? 0ULL : ((1ULL << rem) - 1ULL));
+}
+
+// 64 bits of an LSB-first bitmap starting at bit `bitpos` (wave-uniform), masked by `act`.
+__device__ __forceinline__ u64 load_bits64(const void* bitmap, int64_t bitpos, u64 act) {
+  if (act == 0) return 0;
+  uint64_t abs = ((uint64_t)(uintptr_t)bitmap << 3) + (uint64_t)bitpos;
+  const u64* p = (const u64*)(uintptr_t)((abs >> 6) << 3);
+  int sh = (int)(abs & 63);
+  u64 r = p[0] >> sh;
+  int nbits = 64 - __builtin_clzll(act);
+  if (sh != 0 && sh + nbits > 64) r |= p[1] << (64 - sh);
+  return r & act;
+}
+
+__device__ __forceinline__ int32_t f32_key(uint32_t b) { int32_t s = (int32_t)b; return s ^ (int32_t)(((uint32_t)(s >> 31)) >> 1); }
+__device__ __forceinline__ int64_t f64_key(uint64_t b) { int64_t s = (int64_t)b; return s ^ (int64_t)(((uint64_t)(s >> 63)) >> 1); }
+
+__device__ __forceinline__ void report_error(u64* err, uint32_t ref_order, int64_t row, uint32_t code) {
+  atomicMin(err, ((u64)ref_order << 56) | ((u64)row << 8) | (u64)code);
+}
+
+// value classes the interpreter computes in
+enum VClass { C_I32, C_U32, C_I64, C_U64, C_F32, C_F64, C_BOOL, C_NONE };
+__device__ __forceinline__ int vclass(int t) {
+  switch (t) {
+    case T_I8: case T_I16: case T_I32: return C_I32;
+    case T_U8: case T_U16: case T_U32: return C_U32;
+    case T_I64: return C_I64; case T_U64: return C_U64;
+    case T_F32: return C_F32; case T_F64: return C_F64; case T_BOOL: return C_BOOL;
+    default: return C_NONE;
+  }
+}
+__device__ __forceinline__ void int_range(int t, int64_t& lo, int64_t& hi) {
+  switch (t) {
+    case T_I8: lo = -128; hi = 127; break; case T_I16: lo = -32768; hi = 32767; break;
+    case T_I32: lo = INT32_MIN; hi = INT32_MAX; break;
+    case T_U8: lo = 0; hi = 255; break; case T_U16: lo = 0; hi = 65535; break;
+    default: lo = 0; hi = 4294967295LL; break;
+  }
+}
+
+#define PACK64(lo, hi) (((uint64_t)(hi) << 32) | (uint64_t)(lo))
+
+// ------------------------------------------------------------------------------------------------
+// The interpreter.  One call evaluates the whole program for the 64*R rows of one wave.
+// Register state per lane: lo[R] (+ hi[R] when WIDE) = value of the lane's R rows; bitsv / validv =
+// boolean value / validity of those rows packed one bit per slot (bit j <-> row w0 + 64 j + lane), so a
+// boolean AND/OR over all R rows is one VALU op.  All arrays are indexed with compile-time constants
+// only (loops fully unrolled) so they live in VGPRs.  WIDE=false instantiations carry no 64-bit types.
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK, int R, bool WIDE>
+struct Interp {
+  static constexpr int NW = BLOCK / 64;
+  static constexpr int RH = WIDE ? R : 1;
+  static_assert(R <= 32, "slot flags are packed in 32-bit registers");
+
+  uint32_t lo[R], hi[RH];
+  uint32_t bitsv, validv, actv;
+
+  int64_t w0;        // first row of the wave (uniform)
+  int64_t nrows;
+  int nact;          // active rows in [w0, w0 + 64R) (uniform)
+  int lane, wv;
+
+  __device__ __forceinline__ void set_rows(int64_t tile_start, int64_t nrows_, int lane_, int wv_) {
+    lane = lane_; wv = wv_; nrows = nrows_;
+    w0 = tile_start + (int64_t)wv * 64 * R;
+    int64_t rem = nrows - w0;
+    nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
+    actv = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
+  }
+  __device__ __forceinline__ int off(int j) const {  // clamped element offset of (j, lane) inside the wave's rows
+    int o = j * 64 + lane;
+    return o < nact ? o : nact - 1;
+  }
+  __device__ __forceinline__ u64 group_act(int j) const { return active_mask(w0 + 64 * j, nrows); }
+  // per-lane flags (bit j) from a bitmap
+  __device__ __forceinline__ uint32_t fetch_flags(const void* bitmap, int64_t bit_offset) const {
+    uint32_t f = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      u64 wd = load_bits64(bitmap, bit_offset + w0 + 64 * j, group_act(j));
+      f |= (uint32_t)((wd >> lane) & 1) << j;
+    }
+    return f;
+  }
+
+  // ---- operand fetch ---------------------------------------------------------------------------
+  __device__ __forceinline__ void fetch_col(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) l[j] = 0;
+#pragma unroll
+    for (int j = 0; j < RH; ++j) h[j] = 0;
+    b = 0;
+    if (nact > 0) {
+      switch (c.type) {
+        case T_I8: { const int8_t* p = (const int8_t*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[off(j)]; } break;
+        case T_U8: { const uint8_t* p = (const uint8_t*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = p[off(j)]; } break;
+        case T_I16: { const int16_t* p = (const int16_t*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[off(j)]; } break;
+        case T_U16: { const uint16_t* p = (const uint16_t*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = p[off(j)]; } break;
+        case T_I32: case T_U32: case T_F32: { const uint32_t* p = (const uint32_t*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = p[off(j)]; } break;
+        case T_I64: case T_U64: case T_F64:
+          if constexpr (WIDE) { const uint2* p = (const uint2*)c.values + w0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) { uint2 x = p[off(j)]; l[j] = x.x; h[j] = x.y; } }
+          break;
+        case T_BOOL: b = fetch_flags(c.values, c.bool_bit_offset); break;
+        default: break;
+      }
+    }
+    v = c.validity ? (fetch_flags(c.validity, c.validity_bit_offset) & actv) : actv;
+  }
+
+  // convert values from the class of `from_t` to the class of `to_t` in place: exactly the widenings the
+  // coercion table RU/compute_value.rs:350-431 can request, plus numeric -> Boolean (value != 0)
+  __device__ __forceinline__ void convert(int from_t, int to_t, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b) {
+    const int from = vclass(from_t), to = vclass(to_t);
+    if (from == to || from == C_BOOL || from == C_NONE) return;
+    if (to == C_BOOL) {
+      b = 0;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        bool nz;
+        if (from == C_I32 || from == C_U32) nz = l[j] != 0;
+        else if (from == C_F32) nz = __uint_as_float(l[j]) != 0.0f;
+        else if constexpr (WIDE) {
+          if (from == C_F64) nz = __longlong_as_double((long long)PACK64(l[j], h[j])) != 0.0;
+          else nz = (l[j] | h[j]) != 0;
+        } else nz = false;
+        b |= (uint32_t)nz << j;
+      }
+      return;
+    }
+    if (to == C_F32) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) l[j] = __float_as_uint(from == C_I32 ? (float)(int32_t)l[j] : (float)l[j]);   // round-to-nearest-even
+      return;
+    }
+    if (to == C_I32 || to == C_U32) return;   // u8/u16 -> i32: same bits
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        uint64_t x;
+        if (to == C_F64) {
+          double d;
+          switch (from) {
+            case C_I32: d = (double)(int32_t)l[j]; break; case C_U32: d = (double)l[j]; break;
+            case C_I64: d = (double)(int64_t)PACK64(l[j], h[j]); break; case C_U64: d = (double)PACK64(l[j], h[j]); break;
+            default: d = (double)__uint_as_float(l[j]); break;
+          }
+          x = (uint64_t)__double_as_longlong(d);
+        } else {  // I64 / U64 from a 32-bit integer class
+          x = from == C_I32 ? (uint64_t)(int64_t)(int32_t)l[j] : (uint64_t)l[j];
+        }
+        l[j] = (uint32_t)x; h[j] = (uint32_t)(x >> 32);
+      }
+    }
+  }
+
+  // ---- arithmetic: arrow-arith numeric::{add,sub,mul,div,rem}; checked for integers ----------------
+  __device__ __forceinline__ void arith(int op, int t, bool rev, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], u64* err, uint32_t ref_order) {
+    const int cls = vclass(t);
+    int errj = -1; uint32_t errc = 0;   // first offending slot of this lane (= its smallest row)
+#define BAD(code) do { if (live && errj < 0) { errj = j; errc = (code); } } while (0)
+    if (cls == C_I32) {
+      int64_t tlo, thi; int_range(t, tlo, thi);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int32_t x = (int32_t)lo[j], y = (int32_t)bl[j];
+        const int32_t a = rev ? y : x, b = rev ? x : y;
+        const bool live = (validv >> j) & 1;
+        int64_t w;
+        switch (op) {
+          case OP_ADD: w = (int64_t)a + b; break;
+          case OP_SUB: w = (int64_t)a - b; break;
+          case OP_MUL: w = (int64_t)a * b; break;
+          case OP_DIV: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (a == INT32_MIN && b == -1) w = 2147483648LL; else w = a / b; break;
+          default: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (b == -1) { if ((int64_t)a == tlo) BAD(DE_OVERFLOW); w = 0; } else w = a % b; break;
+        }
+        if (w < tlo || w > thi) BAD(DE_OVERFLOW);
+        lo[j] = (uint32_t)w;
+      }
+    } else if (cls == C_U32) {
+      int64_t tlo, thi; int_range(t, tlo, thi);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const uint32_t x = lo[j], y = bl[j];
+        const uint32_t a = rev ? y : x, b = rev ? x : y;
+        const bool live = (validv >> j) & 1;
+        int64_t w;
+        switch (op) {
+          case OP_ADD: w = (int64_t)a + b; break;
+          case OP_SUB: w = (int64_t)a - b; break;
+          case OP_MUL: { uint64_t pr = (uint64_t)a * b; w = pr > 0x7fffffffffffffffULL ? -1 : (int64_t)pr; } break;
+          case OP_DIV: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a / b; break;
+          default: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a % b; break;
+        }
+        if (w < tlo || w > thi) BAD(DE_OVERFLOW);
+        lo[j] = (uint32_t)w;
+      }
+    } else if (cls == C_F32) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const float x = __uint_as_float(lo[j]), y = __uint_as_float(bl[j]);
+        const float a = rev ? y : x, b = rev ? x : y;
+        float w;
+        switch (op) {
+          case OP_ADD: w = a + b; break; case OP_SUB: w = a - b; break; case OP_MUL: w = a * b; break;
+          case OP_DIV: w = a / b; break; default: w = fmodf(a, b); break;
+        }
+        lo[j] = __float_as_uint(w);
+      }
+    } else if constexpr (WIDE) {
+      if (cls == C_I64) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const long long x = (long long)PACK64(lo[j], hi[j]), y = (long long)PACK64(bl[j], bh[j]);
+          const long long a = rev ? y : x, b = rev ? x : y;
+          long long w = 0;
+          const bool live = (validv >> j) & 1;
+          bool o = false;
+          switch (op) {
+            case OP_ADD: o = __builtin_saddll_overflow(a, b, &w); break;
+            case OP_SUB: o = __builtin_ssubll_overflow(a, b, &w); break;
+            case OP_MUL: o = __builtin_smulll_overflow(a, b, &w); break;
+            case OP_DIV: if (b == 0) BAD(DE_DIV_ZERO); else if (a == INT64_MIN && b == -1) o = true; else w = a / b; break;
+            default: if (b == 0) BAD(DE_DIV_ZERO); else if (a == INT64_MIN && b == -1) o = true; else w = a % b; break;
+          }
+          if (o) BAD(DE_OVERFLOW);
+          lo[j] = (uint32_t)(uint64_t)w; hi[j] = (uint32_t)((uint64_t)w >> 32);
+        }
+      } else if (cls == C_U64) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const u64 x = PACK64(lo[j], hi[j]), y = PACK64(bl[j], bh[j]);
+          const u64 a = rev ? y : x, b = rev ? x : y;
+          u64 w = 0;
+          const bool live = (validv >> j) & 1;
+          bool o = false;
+          switch (op) {
+            case OP_ADD: o = __builtin_uaddll_overflow(a, b, &w); break;
+            case OP_SUB: o = __builtin_usubll_overflow(a, b, &w); break;
+            case OP_MUL: o = __builtin_umulll_overflow(a, b, &w); break;
+            case OP_DIV: if (b == 0) BAD(DE_DIV_ZERO); else w = a / b; break;
+            default: if (b == 0) BAD(DE_DIV_ZERO); else w = a % b; break;
+          }
+          if (o) BAD(DE_OVERFLOW);
+          lo[j] = (uint32_t)w; hi[j] = (uint32_t)(w >> 32);
+        }
+      } else if (cls == C_F64) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const double x = __longlong_as_double((long long)PACK64(lo[j], hi[j])), y = __longlong_as_double((long long)PACK64(bl[j], bh[j]));
+          const double a = rev ? y : x, b = rev ? x : y;
+          double w;
+          switch (op) {
+            case OP_ADD: w = a + b; break; case OP_SUB: w = a - b; break; case OP_MUL: w = a * b; break;
+            case OP_DIV: w = a / b; break; default: w = fmod(a, b); break;
+          }
+          const uint64_t u = (uint64_t)__double_as_longlong(w);
+          lo[j] = (uint32_t)u; hi[j] = (uint32_t)(u >> 32);
+        }
+      }
+    }
+#undef BAD
+    // arrow's try_binary / try_unary stop at the first offending valid element: report (node, row, kind)
+    if (__any(errj >= 0)) { if (errj >= 0) report_error(err, ref_order, w0 + 64 * errj + lane, errc); }
+  }
+
+  // ---- comparisons: arrow-ord cmp::*; floats by IEEE totalOrder ------------------------------------
+  __device__ __forceinline__ void compare(int op, int t, bool rev, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], uint32_t bb) {
+    const int cls = vclass(t);
+    uint32_t ltv = 0, eqv = 0;
+    if (cls == C_BOOL) {
+      const uint32_t a = rev ? bb : bitsv, b = rev ? bitsv : bb;
+      ltv = ~a & b; eqv = ~(a ^ b);
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        bool l_ = false, e_ = false;
+        if (cls == C_I32) { const int32_t x = (int32_t)lo[j], y = (int32_t)bl[j]; const int32_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
+        else if (cls == C_U32) { const uint32_t x = lo[j], y = bl[j]; const uint32_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
+        else if (cls == C_F32) { const int32_t x = f32_key(lo[j]), y = f32_key(bl[j]); const int32_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
+        else if constexpr (WIDE) {
+          if (cls == C_I64) { const int64_t x = (int64_t)PACK64(lo[j], hi[j]), y = (int64_t)PACK64(bl[j], bh[j]); const int64_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
+          else if (cls == C_U64) { const uint64_t x = PACK64(lo[j], hi[j]), y = PACK64(bl[j], bh[j]); const uint64_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
+          else { const int64_t x = f64_key(PACK64(lo[j], hi[j])), y = f64_key(PACK64(bl[j], bh[j])); const int64_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
+        }
+        ltv |= (uint32_t)l_ << j; eqv |= (uint32_t)e_ << j;
+      }
+    }
+    uint32_t r;
+    switch (op) {
+      case OP_EQ: r = eqv; break; case OP_NE: r = ~eqv; break; case OP_LT: r = ltv; break;
+      case OP_LE: r = ltv | eqv; break; case OP_GT: r = ~(ltv | eqv); break; default: r = ~ltv; break;
+    }
+    bitsv = r & actv;
+  }
+
+  // ---- Utf8 comparison of a column against a scalar string or another column ------------------------
+  __device__ __forceinline__ void strcmp_op(int cmp, const ColRef& c, const uint8_t* rhs_bytes, int64_t rhs_len,
+                                            const ColRef* rhs_col, bool rev) {
+    uint32_t ltv = 0, eqv = 0;
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+      if ((actv >> j) & 1) {
+        const int32_t* offs = (const int32_t*)c.values + w0 + 64 * j + lane;
+        const int32_t s0 = offs[0], s1 = offs[1];
+        const uint8_t* a = (const uint8_t*)c.data + s0; int64_t alen = s1 - s0;
+        const uint8_t* b = rhs_bytes; int64_t blen = rhs_len;
+        if (rhs_col) {
+          const int32_t* ro = (const int32_t*)rhs_col->values + w0 + 64 * j + lane;
+          b = (const uint8_t*)rhs_col->data + ro[0]; blen = ro[1] - ro[0];
+        }
+        if (rev) { const uint8_t* t = a; a = b; b = t; const int64_t tl = alen; alen = blen; blen = tl; }
+        const int64_t m = alen < blen ? alen : blen;
+        int c3 = 0;
+        for (int64_t k = 0; k < m; ++k) { const int d = (int)a[k] - (int)b[k]; if (d) { c3 = d; break; } }
+        if (c3 == 0) c3 = (alen > blen) - (alen < blen);
+        ltv |= (uint32_t)(c3 < 0) << j; eqv |= (uint32_t)(c3 == 0) << j;
+      }
+    }
+    uint32_t r;
+    switch (cmp) {
+      case OP_EQ: r = eqv; break; case OP_NE: r = ~eqv; break; case OP_LT: r = ltv; break;
+      case OP_LE: r = ltv | eqv; break; case OP_GT: r = ~(ltv | eqv); break; default: r = ~ltv; break;
+    }
+    bitsv = r & actv;
+  }
+
+  // ---- the program loop --------------------------------------------------------------------------
+  // numeric temporaries live in LDS: tmp_flags [slot][BLOCK] validity flags, tmp_num [slot][2][R][BLOCK] values
+  template <typename StoreFn>
+  __device__ __forceinline__ void run(const ProgramBlock& pb, u64* err, uint32_t* tmp_flags, uint32_t* tmp_num, StoreFn&& store) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) lo[j] = 0;
+#pragma unroll
+    for (int j = 0; j < RH; ++j) hi[j] = 0;
+    bitsv = 0; validv = actv;
+    int acc_type = T_BOOL;
+    const int tix = wv * 64 + lane;
+    uint32_t bl[R], bh[RH]; uint32_t bb = 0, bv = actv;
+    uint32_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0, tv0 = 0, tv1 = 0, tv2 = 0, tv3 = 0;   // boolean temporaries
+    static_assert(MAX_BOOL_TEMPS == 4, "boolean temporaries are four named registers");
+    for (int pc = 0; pc < pb.n_instr; ++pc) {
+      const Instr in = pb.prog[pc];
+      const bool rev = in.flags & IF_REV;
+      if (in.src_kind == SRC_COL) {
+        fetch_col(pb.refs[in.src_idx], bl, bh, bb, bv);
+        if (in.op != OP_STRCMP) convert(in.src_type, in.type, bl, bh, bb);
+      } else if (in.src_kind == SRC_CONST) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) bl[j] = (uint32_t)in.imm;
+#pragma unroll
+        for (int j = 0; j < RH; ++j) bh[j] = (uint32_t)(in.imm >> 32);
+        bb = (in.imm & 1) ? actv : 0; bv = actv;
+      } else if (in.src_kind == SRC_TEMP) {
+        if (vclass(in.src_type) == C_BOOL) {
+          switch (in.src_idx) {
+            case 0: bb = tb0; bv = tv0; break; case 1: bb = tb1; bv = tv1; break;
+            case 2: bb = tb2; bv = tv2; break; default: bb = tb3; bv = tv3; break;
+          }
+        } else {
+          bb = 0; bv = tmp_flags[(size_t)in.src_idx * BLOCK + tix];
+          const uint32_t* tl = tmp_num + (size_t)(in.src_idx * 2) * R * BLOCK;
+#pragma unroll
+          for (int j = 0; j < R; ++j) bl[j] = tl[j * BLOCK + tix];
+          if constexpr (WIDE) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) bh[j] = tl[(size_t)R * BLOCK + j * BLOCK + tix];
+          }
+          convert(in.src_type, in.type, bl, bh, bb);
+        }
+      }
+      switch (in.op) {
+        case OP_LOAD:
+#pragma unroll
+          for (int j = 0; j < R; ++j) lo[j] = bl[j];
+#pragma unroll
+          for (int j = 0; j < RH; ++j) hi[j] = bh[j];
+          bitsv = bb; validv = bv; acc_type = in.type;
+          break;
+        case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_REM:
+          validv &= bv;
+          arith(in.op, in.type, rev, bl, bh, err, in.ref_order);
+          acc_type = in.type;
+          break;
+        case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE:
+          validv &= bv;
+          compare(in.op, in.type, rev, bl, bh, bb);
+          acc_type = T_BOOL;
+          break;
+        case OP_AND: bitsv &= bb; validv &= bv; break;
+        case OP_OR: bitsv |= bb; validv &= bv; break;
+        case OP_CAST: convert(in.src_type, in.type, lo, hi, bitsv); acc_type = in.type; break;
+        case OP_TOBOOL: convert(in.src_type, T_BOOL, lo, hi, bitsv); bitsv &= actv; acc_type = T_BOOL; break;
+        case OP_SPILL: {
+          if (vclass(in.type) == C_BOOL) {
+            switch (in.src_idx) {
+              case 0: tb0 = bitsv; tv0 = validv; break; case 1: tb1 = bitsv; tv1 = validv; break;
+              case 2: tb2 = bitsv; tv2 = validv; break; default: tb3 = bitsv; tv3 = validv; break;
+            }
+          } else {
+            tmp_flags[(size_t)in.src_idx * BLOCK + tix] = validv;
+            uint32_t* tl = tmp_num + (size_t)(in.src_idx * 2) * R * BLOCK;
+#pragma unroll
+            for (int j = 0; j < R; ++j) tl[j * BLOCK + tix] = lo[j];
+            if constexpr (WIDE) {
+#pragma unroll
+              for (int j = 0; j < R; ++j) tl[(size_t)R * BLOCK + j * BLOCK + tix] = hi[j];
+            }
+          }
+        } break;
+        case OP_STRCMP: {
+          const int cmp = (int)(in.imm >> 56);
+          const bool rhs_is_col = in.flags & IF_STR_RHS_COL;
+          const int ridx = (int)(in.imm & 0xffff);
+          uint32_t rv = actv;
+          if (rhs_is_col && pb.refs[ridx].validity) rv = fetch_flags(pb.refs[ridx].validity, pb.refs[ridx].validity_bit_offset) & actv;
+          strcmp_op(cmp, pb.refs[in.src_idx], rhs_is_col ? nullptr : pb.strs[ridx].bytes, rhs_is_col ? 0 : pb.strs[ridx].len,
+                    rhs_is_col ? &pb.refs[ridx] : nullptr, rev);
+          validv = bv & rv;
+          acc_type = T_BOOL;
+        } break;
+        case OP_STORE: store(in.src_idx, acc_type, *this); break;
+        default: break;
+      }
+    }
+  }
+};
+
+// LDS scratch for interpreter temporaries (each thread only touches its own slots: no barriers needed)
+template <int BLOCK, int R, int NUM_TEMPS>
+struct TempLds {
+  uint32_t flags[NUM_TEMPS > 0 ? NUM_TEMPS * BLOCK : 1];
+  uint32_t num[NUM_TEMPS > 0 ? NUM_TEMPS * 2 * R * BLOCK : 1];
+};
+
+// ------------------------------------------------------------------------------------------------
+// filter_fused_kernel: predicate + order-preserving compaction of every fixed-width column, one pass.
+//   P(i): ticket -> interpret predicate -> ballots to LDS -> tile count -> publish AGGREGATE
+//   C(i): look-back -> tile base -> per column: load 64R rows per wave, store the selected ones
+// The loop runs P(i+1) before C(i).
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
+__global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams p) {
+  constexpr int NW = BLOCK / 64;
+  constexpr int64_t TILE = (int64_t)BLOCK * R;
+  __shared__ u64 s_mask[2][R][NW];
+  __shared__ unsigned s_wave_cnt[2][NW];
+  __shared__ unsigned s_tot[2];
+  __shared__ int64_t s_tile[2];
+  __shared__ u64 s_base;
+  __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
+
+  auto P = [&](int buf) {
+    if (tid == 0) s_tile[buf] = (int64_t)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const int64_t tile = s_tile[buf];
+    if (tile >= ntiles) return;
+    Interp<BLOCK, R, WIDE> it;
+    it.set_rows(tile * TILE, p.nrows, lane, wv);
+    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE>&) {});
+    const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const u64 m = __ballot((selv >> j) & 1);
+      if (lane == 0) {
+        s_mask[buf][j][wv] = m;
+        if (p.sel_mask && it.w0 + 64 * j < p.nrows) p.sel_mask[(it.w0 >> 6) + j] = m;
+      }
+      cnt += __popcll(m);
+    }
+    if (lane == 0) s_wave_cnt[buf][wv] = cnt;
+    __syncthreads();
+    if (wv == 0) {
+      unsigned c = (lane < NW) ? s_wave_cnt[buf][lane] : 0u;
+      u64 tot = wave_sum((u64)c);
+      if (lane == 0) {
+        s_tot[buf] = (unsigned)tot;
+        st_store(&p.status[tile], (tile == 0 ? ST_INC : ST_AGG) | tot);
+      }
+    }
+  };
+
+  auto C = [&](int buf) {
+    const int64_t tile = s_tile[buf];
+    if (wv == 0) {
+      u64 excl = 0;
+      if (tile > 0) {
+        excl = lookback_exclusive(p.status, tile, 0, lane);
+        if (lane == 0) st_store(&p.status[tile], ST_INC | (excl + s_tot[buf]));
+      }
+      if (lane == 0) { s_base = excl; if (tile == ntiles - 1) *p.total = excl + s_tot[buf]; }
+    }
+    __syncthreads();
+    u64 off0 = s_base;
+    for (int w = 0; w < wv; ++w) off0 += s_wave_cnt[buf][w];
+    const int64_t w0 = tile * TILE + (int64_t)wv * 64 * R;
+    int64_t rem = p.nrows - w0;
+    const int nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
+    if (p.grp_base && lane == 0 && nact > 0) {
+      u64 run = off0;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (w0 + 64 * j < p.nrows) p.grp_base[(w0 >> 6) + j] = run;
+        run += __popcll(s_mask[buf][j][wv]);
+      }
+    }
+    if (nact > 0) {
+      for (int c = 0; c < p.n_out; ++c) {
+        const OutCol oc = p.outs[c];
+        switch (oc.width) {
+#define COPY_COL(TY, CH)                                                                              \
+  { const TY* src = (const TY*)oc.in + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;            \
+    _Pragma("unroll") for (int j0 = 0; j0 < R; j0 += CH) {                                             \
+      TY v[CH];                                                                                        \
+      _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) { int o = (j0 + jj) * 64 + lane; v[jj] = src[o < nact ? o : nact - 1]; } \
+      _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) {                                              \
+        const u64 m = s_mask[buf][j0 + jj][wv];                                                        \
+        if ((m >> lane) & 1) dst[run + lane_rank(m)] = v[jj];                                          \
+        run += __popcll(m); } } }
+          case 1: COPY_COL(uint8_t, R) break;
+          case 2: COPY_COL(uint16_t, R) break;
+          case 4: COPY_COL(uint32_t, R) break;
+          case 8: COPY_COL(uint2, (R >= 8 ? 8 : R)) break;
+          default: {   // 16-byte values (decimal128 ...): no private array (it would be promoted to LDS)
+            const uint4* src = (const uint4*)oc.in + w0; uint4* dst = (uint4*)oc.out + off0; unsigned run = 0;
+#pragma unroll
+            for (int j0 = 0; j0 < R; j0 += 2) {
+              const int o0 = j0 * 64 + lane, o1 = o0 + 64;
+              const uint4 v0 = src[o0 < nact ? o0 : nact - 1], v1 = src[o1 < nact ? o1 : nact - 1];
+              const u64 m0 = s_mask[buf][j0][wv], m1 = s_mask[buf][j0 + 1][wv];
+              if ((m0 >> lane) & 1) dst[run + lane_rank(m0)] = v0;
+              run += __popcll(m0);
+              if ((m1 >> lane) & 1) dst[run + lane_rank(m1)] = v1;
+              run += __popcll(m1);
+            }
+          } break;
+#undef COPY_COL
+        }
+      }
+    }
+  };
+
+  P(0);
+  int itn = 0;
+  while (true) {
+    if (s_tile[itn & 1] >= ntiles) break;
+    P((itn + 1) & 1);
+    C(itn & 1);
+    ++itn;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// project_kernel: evaluate every SelectItem expression densely (no compaction, no inter-tile state)
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
+__global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
+  constexpr int NW = BLOCK / 64;
+  constexpr int64_t TILE = (int64_t)BLOCK * R;
+  __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    Interp<BLOCK, R, WIDE> it;
+    it.set_rows(tile * TILE, p.nrows, lane, wv);
+    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [&](int out_idx, int acc_type, Interp<BLOCK, R, WIDE>& s) {
+      const ProjOut po = p.outs[out_idx];
+      if (s.nact <= 0) return;
+      const int cls = vclass(acc_type);
+      if (cls == C_BOOL) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const u64 m = __ballot((s.bitsv >> j) & 1);
+          if (lane == 0 && s.w0 + 64 * j < p.nrows) ((u64*)po.values)[(s.w0 >> 6) + j] = m;
+        }
+      } else {
+        switch (acc_type) {
+#define STORE_COL(TY, EXPR)                                                              \
+  { TY* dst = (TY*)po.values + s.w0;                                                     \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) if ((s.actv >> j) & 1) dst[j * 64 + lane] = (EXPR); }
+          case T_I8: case T_U8: STORE_COL(uint8_t, (uint8_t)s.lo[j]) break;
+          case T_I16: case T_U16: STORE_COL(uint16_t, (uint16_t)s.lo[j]) break;
+          case T_I32: case T_U32: case T_F32: STORE_COL(uint32_t, s.lo[j]) break;
+          default: if constexpr (WIDE) STORE_COL(uint2, make_uint2(s.lo[j], s.hi[j])) break;
+#undef STORE_COL
+        }
+      }
+      if (po.validity) {
+        unsigned nulls = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const u64 v = __ballot((s.validv >> j) & 1);
+          const u64 a = s.group_act(j);
+          if (a) { if (lane == 0) po.validity[(s.w0 >> 6) + j] = v; nulls += __popcll(a & ~v); }
+        }
+        if (nulls && lane == 0) atomicAdd(po.null_count, (u64)nulls);
+      }
+    });
+    __syncthreads();   // temporaries in LDS are reused by the next tile
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit_compact_kernel: out bit k = in bit of the k-th selected row (Boolean values, validity bitmaps).
+// One wave per 64*R rows: each 64-row group is compressed with one ds_permute + ballot, the groups are
+// appended to a per-wave bit stream; whole 32-bit words are stored, the first/last (shared) words of a
+// chunk are merged with atomicOr into the zero-initialised output.
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK, int R>
+__global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactParams p) {
+  constexpr int NW = BLOCK / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t nchunks = (p.nrows + 64 * R - 1) / (64 * R);
+  for (int64_t chunk = (int64_t)blockIdx.x * NW + wv; chunk < nchunks; chunk += (int64_t)gridDim.x * NW) {
+    const int64_t w0 = chunk * 64 * R;
+    const u64 pos0 = p.grp_base[w0 >> 6];       // output bit position of the chunk's first selected row
+    // stream state (wave-uniform): `total` pending bits in {hi:lo}, the first of them at bit `wpos*32`
+    const int shift0 = (int)(pos0 & 31);
+    int64_t wpos = (int64_t)(pos0 >> 5);
+    u64 lo64 = 0; u64 hi64 = 0; int total = shift0;   // shift0 leading zero bits belong to earlier rows
+    bool head_shared = shift0 != 0;
+    unsigned zeros = 0;
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+      const int64_t r0 = w0 + 64 * j;
+      const u64 act = active_mask(r0, p.nrows);
+      if (!act) break;
+      const u64 m = p.sel_mask[r0 >> 6] & act;
+      const int cnt = __popcll(m);
+      if (cnt == 0) continue;
+      const u64 inb = load_bits64(p.in_bits, p.in_bit_offset + r0, act);
+      const int mybit = (int)((inb >> lane) & 1);
+      const bool sel = (m >> lane) & 1;
+      // compress: selected lane -> lane rank(m); unselected lanes take the remaining slots from the top
+      const unsigned dst = sel ? lane_rank(m) : 63u - lane_rank(~m);
+      const int got = __builtin_amdgcn_ds_permute((int)(dst << 2), mybit);
+      u64 comp = __ballot(got != 0);
+      if (cnt < 64) comp &= (1ULL << cnt) - 1ULL;
+      zeros += cnt - __popcll(comp);
+      // append cnt bits (total < 32 here)
+      lo64 |= comp << total;
+      hi64 = total ? (comp >> (64 - total)) : 0ULL;
+      total += cnt;
+      while (total >= 32) {
+        const unsigned wordv = (unsigned)lo64;
+        if (lane == 0) { if (head_shared) atomicOr(&p.out_bits[wpos], wordv); else p.out_bits[wpos] = wordv; }
+        head_shared = false;
+        lo64 = (lo64 >> 32) | (hi64 << 32); hi64 >>= 32;
+        total -= 32; ++wpos;
+      }
+    }
+    if (total > 0 && lo64 != 0) { if (lane == 0) atomicOr(&p.out_bits[wpos], (unsigned)lo64); }
+    if (p.zero_count && zeros && lane == 0) atomicAdd(p.zero_count, (u64)zeros);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Utf8 filter, kernel 1: byte length of every selected row -> new offsets.  A chained scan over tiles
+// of 64*G*NW rows carries the running byte total; row positions come from grp_base.
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK, int G>
+__global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p) {
+  constexpr int NW = BLOCK / 64;
+  constexpr int64_t TILE = (int64_t)64 * G * NW;
+  __shared__ u64 s_wave_bytes[NW];
+  __shared__ u64 s_base_bytes;
+  __shared__ int64_t s_tile;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
+  while (true) {
+    if (tid == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile >= ntiles) break;
+    const int64_t w0 = tile * TILE + (int64_t)wv * 64 * G;
+    u64 len[G]; u64 msk[G];
+    u64 bytes = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int64_t r0 = w0 + 64 * g;
+      const u64 act = active_mask(r0, p.nrows);
+      msk[g] = act ? (p.sel_mask[r0 >> 6] & act) : 0ULL;
+      len[g] = 0;
+      if ((msk[g] >> lane) & 1) { const int32_t* o = p.in_offsets + r0 + lane; len[g] = (u64)(o[1] - o[0]); }
+      bytes += len[g];
+    }
+    bytes = wave_sum(bytes);
+    if (lane == 0) s_wave_bytes[wv] = bytes;
+    __syncthreads();
+    if (wv == 0) {
+      u64 tb = 0;
+      for (int w = 0; w < NW; ++w) tb += s_wave_bytes[w];
+      u64 excl = 0;
+      if (lane == 0) st_store(&p.byte_status[tile], (tile == 0 ? ST_INC : ST_AGG) | tb);
+      if (tile > 0) {
+        excl = lookback_exclusive(p.byte_status, tile, 0, lane);
+        if (lane == 0) st_store(&p.byte_status[tile], ST_INC | (excl + tb));
+      }
+      if (lane == 0) {
+        s_base_bytes = excl;
+        if (tile == ntiles - 1) { *p.total_bytes = excl + tb; p.out_offsets[p.rows_out] = (int32_t)(excl + tb); }
+      }
+    }
+    __syncthreads();
+    u64 boff = s_base_bytes;
+    for (int w = 0; w < wv; ++w) boff += s_wave_bytes[w];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int64_t r0 = w0 + 64 * g;
+      if (msk[g]) {
+        u64 inc = len[g];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u64 t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if ((msk[g] >> lane) & 1) p.out_offsets[p.grp_base[r0 >> 6] + lane_rank(msk[g])] = (int32_t)(boff + inc - len[g]);
+        boff += __shfl(inc, 63, 64);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Utf8 filter, kernel 2: copy the bytes of the selected rows. One wave per 64 rows: the selected rows
+// of the group are contiguous in the output, each is copied by the whole wave (coalesced for the
+// >= 64 B strings of the wide-string data set; short strings are handled lane-per-row).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
+  constexpr int NW = BLOCK / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ngroups = (p.nrows + 63) >> 6;
+  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < ngroups; g += (int64_t)gridDim.x * NW) {
+    const int64_t r0 = g << 6;
+    const u64 m = p.sel_mask[g] & active_mask(r0, p.nrows);
+    if (!m) continue;
+    const bool sel = (m >> lane) & 1;
+    int32_t s0 = 0, s1 = 0;
+    if (sel) { const int32_t* o = p.in_offsets + r0 + lane; s0 = o[0]; s1 = o[1]; }
+    const int cnt = __popcll(m);
+    const unsigned dst = sel ? lane_rank(m) : 63u - lane_rank(~m);
+    // lane k now describes the selected row of rank k
+    const int src0 = __builtin_amdgcn_ds_permute((int)(dst << 2), s0);
+    const int len0 = __builtin_amdgcn_ds_permute((int)(dst << 2), s1 - s0);
+    const int64_t dbase = p.out_offsets[p.grp_base[g]];   // bytes of this group are contiguous in the output
+    // exclusive prefix of the lengths = destination of each row relative to dbase
+    int inc = lane < cnt ? len0 : 0;
+    const int mylen = inc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    const int dst0 = inc - mylen;
+    const int group_bytes = __shfl(inc, 63, 64);
+    const int maxlen = group_bytes;  // upper bound used only to pick a strategy
+    if (maxlen <= 64 * 16) {
+      // short strings: lane per row
+      if (lane < cnt) for (int b = 0; b < mylen; ++b) p.out_data[dbase + dst0 + b] = p.in_data[(int64_t)src0 + b];
+    } else {
+      for (int k = 0; k < cnt; ++k) {
+        const int s = __shfl(src0, k, 64), l = __shfl(len0, k, 64), d = __shfl(dst0, k, 64);
+        for (int b = lane; b < l; b += 64) p.out_data[dbase + d + b] = p.in_data[(int64_t)s + b];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers (extern, used by engine.cpp)
+// ------------------------------------------------------------------------------------------------
+// tile_kind 0: 1024 threads x 16 rows, 32-bit types only, no numeric temporaries (the streaming path)
+// tile_kind 1:  256 threads x  8 rows, 32-bit types only
+// tile_kind 2:  256 threads x  8 rows, all types, numeric temporaries in LDS (general path)
+hipError_t launch_filter(const FilterParams& p, int tile_kind, int grid, hipStream_t stream) {
+  switch (tile_kind) {
+    case 0: hipLaunchKernelGGL((filter_fused_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
+    case 1: hipLaunchKernelGGL((filter_fused_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((filter_fused_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_project(const ProjectParams& p, int tile_kind, int grid, hipStream_t stream) {
+  switch (tile_kind) {
+    case 0: hipLaunchKernelGGL((project_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
+    case 1: hipLaunchKernelGGL((project_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((project_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((bit_compact_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((utf8_offsets_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((utf8_copy_kernel<256>), dim3(grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace chq

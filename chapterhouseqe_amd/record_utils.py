@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference's `record_utils` module on top of the chq C ABI.
+
+Reference (RU = src/handlers/operator_handler/operators/record_utils):
+
+    pub fn compute_value(rec, table_aliases, expr) -> Result<ArrayDatum>        RU/compute_value.rs:57-61
+    pub fn filter_record(rec, table_aliases, expr) -> Result<RecordBatch>       RU/filter_record.rs:21-25
+    pub fn project_record(fields, record, table_aliases) -> Result<RecordBatch> RU/record_projection.rs:16-20
+
+Same names, same argument order and meaning, same error classes (ChqError.code mirrors the reference's
+error enums, see include/chq.h).  Records are pyarrow RecordBatches (host; staged to HBM by the library) or
+`DeviceRecordBatch`es (already in HBM; results stay there).  Every call runs HIP kernels on the GPU --
+there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import pyarrow as pa
+
+from . import _lib as L
+from . import sqlast as A
+
+_OPS = {A.BinaryOperator.And: 0, A.BinaryOperator.Or: 1, A.BinaryOperator.Plus: 2, A.BinaryOperator.Minus: 3,
+        A.BinaryOperator.Multiply: 4, A.BinaryOperator.Divide: 5, A.BinaryOperator.Modulo: 6,
+        A.BinaryOperator.Eq: 7, A.BinaryOperator.NotEq: 8, A.BinaryOperator.Gt: 9, A.BinaryOperator.GtEq: 10,
+        A.BinaryOperator.Lt: 11, A.BinaryOperator.LtEq: 12}
+_OP_OTHER = 13
+
+
+class ChqError(Exception):
+    """An error returned by the library; `.code` is the chq_status (mirrors the reference's error enums)."""
+
+    def __init__(self, code: int, message: str):
+        self.code = code
+        self.status_name = L.lib().chq_status_name(code).decode()
+        self.message = message
+        super().__init__(f"[{code} {self.status_name}] {message}")
+
+
+# ------------------------------------------------------------------------------------------ context
+class Context:
+    """One per operator instance (the reference processes one batch at a time per instance)."""
+
+    def __init__(self, device_id: int = 0, stream: Optional[int] = None):
+        self._h = C.c_void_p()
+        rc = L.lib().chq_ctx_create(device_id, C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if rc:
+            raise ChqError(rc, f"chq_ctx_create(device {device_id}) failed: no usable MI355X/HIP device")
+        self.device_id = device_id
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_option(self, key: str, value: int) -> None:
+        rc = L.lib().chq_ctx_set_option(self._h, key.encode(), int(value))
+        if rc:
+            raise ChqError(rc, self.last_error())
+
+    def last_error(self) -> str:
+        return L.lib().chq_ctx_last_error(self._h).decode(errors="replace")
+
+    def last_stats(self) -> Dict[str, int]:
+        s = L.CallStats()
+        L.lib().chq_ctx_last_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in L.CallStats._fields_}
+
+    @property
+    def stream(self) -> int:
+        return L.lib().chq_ctx_stream(self._h) or 0
+
+    def close(self) -> None:
+        if self._h:
+            L.lib().chq_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ------------------------------------------------------------------------------------------ batches
+class _CBatch:
+    """ArrowDeviceArray + ArrowSchema pair owned by Python (released on close)."""
+
+    def __init__(self):
+        self.array = L.ArrowDeviceArray()
+        self.schema = L.ArrowSchema()
+
+    def release(self):
+        for s in (self.array.array, self.schema):
+            if s.release:
+                C.CFUNCTYPE(None, C.c_void_p)(s.release)(C.addressof(s))
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def _export_host(rec: pa.RecordBatch) -> _CBatch:
+    cb = _CBatch()
+    rec._export_to_c(C.addressof(cb.array.array), C.addressof(cb.schema))
+    cb.array.device_id = -1
+    cb.array.device_type = L.ARROW_DEVICE_CPU
+    return cb
+
+
+def _import_host(cb: _CBatch) -> pa.RecordBatch:
+    rb = pa.RecordBatch._import_from_c(C.addressof(cb.array.array), C.addressof(cb.schema))  # moves ownership
+    return rb
+
+
+class DeviceRecordBatch:
+    """A record batch resident in HBM (Arrow C Device Data Interface, ARROW_DEVICE_ROCM)."""
+
+    def __init__(self, ctx: Context, cb: _CBatch, keepalive=None):
+        self.ctx = ctx
+        self._cb = cb
+        self._keep = keepalive
+
+    @property
+    def num_rows(self) -> int:
+        return self._cb.array.array.length
+
+    @property
+    def num_columns(self) -> int:
+        return self._cb.array.array.n_children
+
+    @property
+    def column_names(self) -> List[str]:
+        return [self._cb.schema.children[i].contents.name.decode() for i in range(self.num_columns)]
+
+    def column_buffer_address(self, i: int, buffer: int = 1) -> int:
+        """Device address of buffer `buffer` (0 validity, 1 values/offsets, 2 data) of column i."""
+        return self._cb.array.array.children[i].contents.buffers[buffer] or 0
+
+    @staticmethod
+    def from_host(rec: pa.RecordBatch, ctx: Optional[Context] = None) -> "DeviceRecordBatch":
+        ctx = ctx or default_context()
+        src = _export_host(rec)
+        out = _CBatch()
+        rc = L.lib().chq_record_to_device(ctx.handle, C.byref(src.array), C.byref(src.schema), C.byref(out.array), C.byref(out.schema))
+        src.release()
+        if rc:
+            raise ChqError(rc, ctx.last_error())
+        return DeviceRecordBatch(ctx, out)
+
+    @staticmethod
+    def from_device_pointers(columns: Sequence[Tuple[str, str, int]], num_rows: int, ctx: Optional[Context] = None,
+                             keepalive=None) -> "DeviceRecordBatch":
+        """Wrap caller-owned HBM buffers (e.g. torch tensors) without copying.
+        `columns`: (name, arrow_format, device_address_of_values) for non-null fixed-width columns."""
+        ctx = ctx or default_context()
+        descs = (L.ColumnDesc * max(1, len(columns)))()
+        for i, (name, fmt, addr) in enumerate(columns):
+            descs[i].name = name.encode()
+            descs[i].format = fmt.encode()
+            descs[i].values = addr
+        out = _CBatch()
+        rc = L.lib().chq_wrap_columns(ctx.handle, descs, len(columns), num_rows, L.ARROW_DEVICE_ROCM, C.byref(out.array), C.byref(out.schema))
+        if rc:
+            raise ChqError(rc, ctx.last_error())
+        return DeviceRecordBatch(ctx, out, keepalive)
+
+    def to_host(self) -> pa.RecordBatch:
+        out = _CBatch()
+        rc = L.lib().chq_record_to_host(self.ctx.handle, C.byref(self._cb.array), C.byref(self._cb.schema), C.byref(out.array), C.byref(out.schema))
+        if rc:
+            raise ChqError(rc, self.ctx.last_error())
+        return _import_host(out)
+
+    def release(self) -> None:
+        self._cb.release()
+
+
+Record = Union[pa.RecordBatch, DeviceRecordBatch]
+
+
+# ------------------------------------------------------------------------------------------ expr marshalling
+def _expr_to_c(e: A.Expr):
+    lib = L.lib()
+    if isinstance(e, A.Nested):
+        return lib.chq_expr_nested(_expr_to_c(e.expr))
+    if isinstance(e, A.BinaryOp):
+        return lib.chq_expr_binary_op(_expr_to_c(e.left), _OPS.get(e.op, _OP_OTHER), e.op.value.encode(), _expr_to_c(e.right))
+    if isinstance(e, A.ValueExpr):
+        v = e.value
+        if isinstance(v, A.Number):
+            return lib.chq_expr_number(v.text.encode(), int(v.long))
+        if isinstance(v, A.Boolean):
+            return lib.chq_expr_boolean(int(v.value))
+        if isinstance(v, A.SingleQuotedString):
+            b = v.value.encode()
+            return lib.chq_expr_single_quoted_string(b, len(b))
+        return lib.chq_expr_unsupported_value(v.debug.encode())
+    if isinstance(e, A.Identifier):
+        return lib.chq_expr_identifier(e.ident.value.encode())
+    if isinstance(e, A.CompoundIdentifier):
+        arr = (C.c_char_p * max(1, len(e.idents)))(*[i.value.encode() for i in e.idents])
+        return lib.chq_expr_compound_identifier(arr, len(e.idents))
+    if isinstance(e, A.UnsupportedExpr):
+        return lib.chq_expr_unsupported(e.debug.encode())
+    raise TypeError(f"not an Expr: {e!r}")
+
+
+class _Aliases:
+    def __init__(self, table_aliases: Optional[Sequence[Sequence[str]]]):
+        self.ptr = None
+        if table_aliases is None:
+            return
+        self._lists = (L.AliasList * max(1, len(table_aliases)))()
+        self._keep = []
+        for i, al in enumerate(table_aliases):
+            arr = (C.c_char_p * max(1, len(al)))(*[a.encode() for a in al])
+            self._keep.append(arr)
+            self._lists[i].aliases = arr
+            self._lists[i].n = len(al)
+        self._ta = L.TableAliases(self._lists, len(table_aliases))
+        self.ptr = C.pointer(self._ta)
+
+
+def _items_to_c(fields: Sequence[A.SelectItem]):
+    lib = L.lib()
+    items = (L.SelectItem * max(1, len(fields)))()
+    exprs = []
+    for i, f in enumerate(fields):
+        if isinstance(f, A.Wildcard):
+            items[i].kind = 0
+        elif isinstance(f, A.QualifiedWildcard):
+            items[i].kind = 1
+        elif isinstance(f, A.UnnamedExpr):
+            items[i].kind = 2
+            items[i].expr = _expr_to_c(f.expr)
+            exprs.append(items[i].expr)
+        elif isinstance(f, A.ExprWithAlias):
+            items[i].kind = 3
+            items[i].expr = _expr_to_c(f.expr)
+            items[i].alias = f.alias.value.encode()
+            exprs.append(items[i].expr)
+        else:
+            raise TypeError(f"not a SelectItem: {f!r}")
+    return items, exprs
+
+
+def _prepare(rec: Record, ctx: Optional[Context]):
+    if isinstance(rec, DeviceRecordBatch):
+        return rec.ctx if ctx is None else ctx, rec._cb, False, True
+    return (ctx or default_context()), _export_host(rec), True, False
+
+
+def _finish(ctx: Context, rc: int, out: _CBatch, device_result: bool):
+    if rc:
+        raise ChqError(rc, ctx.last_error())
+    if device_result:
+        return DeviceRecordBatch(ctx, out)
+    return _import_host(out)
+
+
+# ------------------------------------------------------------------------------------------ the path
+def filter_record(rec: Record, table_aliases: Optional[Sequence[Sequence[str]]], expr: A.Expr, *,
+                  ctx: Optional[Context] = None, device_result: Optional[bool] = None):
+    """RU/filter_record.rs:21-39.  Keeps the rows where `expr` is true (and valid); every column, original
+    order, same schema.  Result residency follows the input unless `device_result` says otherwise."""
+    ctx, src, own_src, on_dev = _prepare(rec, ctx)
+    dev_out = on_dev if device_result is None else device_result
+    e = _expr_to_c(expr)
+    al = _Aliases(table_aliases)
+    out = _CBatch()
+    try:
+        rc = L.lib().chq_filter_record(ctx.handle, C.byref(src.array), C.byref(src.schema), al.ptr, e,
+                                       L.ARROW_DEVICE_ROCM if dev_out else L.ARROW_DEVICE_CPU, C.byref(out.array), C.byref(out.schema))
+    finally:
+        L.lib().chq_expr_free(e)
+        if own_src:
+            src.release()
+    return _finish(ctx, rc, out, dev_out)
+
+
+def project_record(fields: Sequence[A.SelectItem], record: Record, table_aliases: Optional[Sequence[Sequence[str]]], *,
+                   ctx: Optional[Context] = None, device_result: Optional[bool] = None):
+    """RU/record_projection.rs:16-76."""
+    ctx, src, own_src, on_dev = _prepare(record, ctx)
+    dev_out = on_dev if device_result is None else device_result
+    items, exprs = _items_to_c(fields)
+    al = _Aliases(table_aliases)
+    out = _CBatch()
+    try:
+        rc = L.lib().chq_project_record(ctx.handle, items, len(fields), C.byref(src.array), C.byref(src.schema), al.ptr,
+                                        L.ARROW_DEVICE_ROCM if dev_out else L.ARROW_DEVICE_CPU, C.byref(out.array), C.byref(out.schema))
+    finally:
+        for x in exprs:
+            L.lib().chq_expr_free(x)
+        if own_src:
+            src.release()
+    return _finish(ctx, rc, out, dev_out)
+
+
+def filter_project_record(predicate: A.Expr, fields: Sequence[A.SelectItem], record: Record,
+                          table_aliases: Optional[Sequence[Sequence[str]]], *, ctx: Optional[Context] = None,
+                          device_result: Optional[bool] = None):
+    """filter_record followed by project_record on the survivors, without leaving the GPU
+    (the reference's filter -> exchange -> materialize sequence, filter_task.rs:99 + materialize_files_task.rs:110)."""
+    ctx, src, own_src, on_dev = _prepare(record, ctx)
+    dev_out = on_dev if device_result is None else device_result
+    e = _expr_to_c(predicate)
+    items, exprs = _items_to_c(fields)
+    al = _Aliases(table_aliases)
+    out = _CBatch()
+    try:
+        rc = L.lib().chq_filter_project_record(ctx.handle, e, items, len(fields), C.byref(src.array), C.byref(src.schema), al.ptr,
+                                               L.ARROW_DEVICE_ROCM if dev_out else L.ARROW_DEVICE_CPU, C.byref(out.array), C.byref(out.schema))
+    finally:
+        L.lib().chq_expr_free(e)
+        for x in exprs:
+            L.lib().chq_expr_free(x)
+        if own_src:
+            src.release()
+    return _finish(ctx, rc, out, dev_out)
+
+
+def compute_value(rec: Record, table_aliases: Optional[Sequence[Sequence[str]]], expr: A.Expr, *,
+                  ctx: Optional[Context] = None) -> Tuple[pa.Array, bool]:
+    """RU/compute_value.rs:57-344.  Returns (array, is_scalar) like the reference's ArrayDatum."""
+    ctx, src, own_src, _ = _prepare(rec, ctx)
+    e = _expr_to_c(expr)
+    al = _Aliases(table_aliases)
+    out = _CBatch()
+    sc = C.c_int(0)
+    try:
+        rc = L.lib().chq_compute_value(ctx.handle, C.byref(src.array), C.byref(src.schema), al.ptr, e, L.ARROW_DEVICE_CPU,
+                                       C.byref(out.array), C.byref(out.schema), C.byref(sc))
+    finally:
+        L.lib().chq_expr_free(e)
+        if own_src:
+            src.release()
+    if rc:
+        raise ChqError(rc, ctx.last_error())
+    arr = pa.Array._import_from_c(C.addressof(out.array.array), C.addressof(out.schema))
+    return arr, bool(sc.value)
+
+
+def get_record_table_aliases(alias: Optional[str], record) -> List[List[str]]:
+    """RU/record_aliases.rs:12-59: one alias list per column, `[alias]` or `[]`, taken from the producing
+    TableFunc / Table operator."""
+    n = record.num_columns
+    return [[alias] for _ in range(n)] if alias is not None else [[] for _ in range(n)]

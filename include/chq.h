@@ -1,0 +1,194 @@
+/*
+ * chq.h -- C ABI of the MI355X-native filter / projection record kernels for ChapterhouseDB.
+ *
+ * This is the drop-in boundary for ONE path of the reference (alekLukanen/ChapterhouseQE): the
+ * record_utils functions its `filter` and `materialize` operator tasks call once per RecordBatch.
+ * Reference paths are relative to the reference repo root; RU = src/handlers/operator_handler/
+ * operators/record_utils.
+ *
+ *   chq_filter_record   replaces  RU/filter_record.rs:21-25    pub fn filter_record(rec, table_aliases, expr)
+ *                        called at operators/filter_tasks/filter_task.rs:99
+ *   chq_project_record  replaces  RU/record_projection.rs:16-20 pub fn project_record(fields, record, table_aliases)
+ *                        called at operators/materialize_tasks/materialize_files_task.rs:110
+ *   chq_compute_value   replaces  RU/compute_value.rs:57-61     pub fn compute_value(rec, table_aliases, expr)
+ *   chq_expr_*          carry     sqlparser::ast::Expr  (the variants RU/compute_value.rs:62-343 matches on)
+ *   chq_select_item     carries   sqlparser::ast::SelectItem (RU/record_projection.rs:25-69)
+ *   chq_table_aliases   carries   table_aliases: &Vec<Vec<String>> (RU/record_aliases.rs:12-59)
+ *   status codes        mirror    ComputeValueError (RU/compute_value.rs:13-32), FilterRecordError
+ *                                 (RU/filter_record.rs:12-15), ProjectRecordError (RU/record_projection.rs:11-14)
+ *                                 and the ArrowError variants of the arrow-rs 53 kernels behind them.
+ *
+ * Record batches cross the boundary as Arrow C (Device) Data Interface structs (chq_arrow_abi.h): a
+ * struct-typed ArrowDeviceArray with one child per column plus its ArrowSchema.  Inputs may live on
+ * the host (ARROW_DEVICE_CPU; the library stages them to HBM) or already on the GPU (ARROW_DEVICE_ROCM,
+ * zero copy).  Inputs are borrowed for the duration of the call and never modified or released.
+ * Outputs are freshly allocated, owned by the caller and freed through the standard Arrow `release`
+ * callbacks; the caller chooses whether they are returned in HBM (stay on the GPU for the next
+ * operator) or copied back to host memory.
+ *
+ * No torch / C++ types appear here.  All functions are thread-safe per context: one chq_ctx per
+ * operator instance (the reference runs one batch at a time per instance, filter_task.rs:86-125).
+ * Everything is computed by HIP kernels on gfx950; there is no CPU fallback -- a missing or unusable
+ * device is an error (CHQ_ERR_DEVICE).
+ */
+#ifndef CHQ_H
+#define CHQ_H
+
+#include <stdint.h>
+#include "chq_arrow_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHQ_ABI_VERSION 1
+
+/* ---- status codes --------------------------------------------------------------------------- */
+typedef enum chq_status {
+  CHQ_OK = 0,
+  /* ComputeValueError, RU/compute_value.rs:13-32 */
+  CHQ_ERR_VALUE_TYPE_NOT_IMPLEMENTED = 1,
+  CHQ_ERR_EXPRESSION_TYPE_NOT_IMPLEMENTED = 2,
+  CHQ_ERR_BINARY_OPERATOR_NOT_IMPLEMENTED = 3,
+  CHQ_ERR_BINARY_OPERATION_CAST_FAILED = 4,
+  CHQ_ERR_FAILED_TO_PARSE_AS_AN_INTEGER = 5,
+  CHQ_ERR_FAILED_TO_PARSE_AS_A_FLOAT = 6,
+  CHQ_ERR_COLUMN_NOT_FOUND = 7,
+  CHQ_ERR_IDENTIFIER_NOT_FOUND = 8,
+  CHQ_ERR_UNSUPPORTED_TYPE_COERSION = 9,
+  /* FilterRecordError, RU/filter_record.rs:12-15 */
+  CHQ_ERR_CAST_TO_BOOLEAN_ARRAY_FAILED = 10,
+  /* ProjectRecordError, RU/record_projection.rs:11-14 */
+  CHQ_ERR_PROJECT_NOT_IMPLEMENTED = 11,
+  /* ArrowError raised by the arrow-rs kernels the reference calls */
+  CHQ_ERR_ARROW_ARITHMETIC_OVERFLOW = 20,
+  CHQ_ERR_ARROW_DIVIDE_BY_ZERO = 21,
+  CHQ_ERR_ARROW_INVALID_ARGUMENT = 22,
+  CHQ_ERR_ARROW_COMPUTE = 23,
+  CHQ_ERR_ARROW_CAST = 24,
+  /* this implementation */
+  CHQ_ERR_NOT_SUPPORTED = 30,   /* valid in the reference, outside this build's scope */
+  CHQ_ERR_INVALID_HANDLE = 31,
+  CHQ_ERR_DEVICE = 40,          /* HIP runtime / no usable gfx950 device */
+  CHQ_ERR_OUT_OF_MEMORY = 41
+} chq_status;
+
+/* ---- context -------------------------------------------------------------------------------- */
+typedef struct chq_ctx chq_ctx;
+
+/* One context per operator instance.  `hip_stream` is a hipStream_t to run on, or NULL to let the
+ * context create its own non-blocking stream.  Fails with CHQ_ERR_DEVICE when no GPU is usable. */
+chq_status chq_ctx_create(int device_id, void* hip_stream, chq_ctx** out);
+void chq_ctx_destroy(chq_ctx* ctx);
+/* Message of the last failing call on this context (valid until the next call on it). */
+const char* chq_ctx_last_error(const chq_ctx* ctx);
+/* hipStream_t the context launches on. */
+void* chq_ctx_stream(const chq_ctx* ctx);
+/* Tuning knobs: "tile_rows" (0 = auto), "keep_selection_mask". Unknown keys fail. */
+chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value);
+/* Counters of the last filter call: rows in, rows out, tiles, kernel launches. */
+typedef struct chq_call_stats {
+  int64_t rows_in, rows_out, tiles, launches;
+  int64_t bytes_read_alg, bytes_written_alg;   /* algorithmic bytes per SURVEY.md section 8(d) */
+} chq_call_stats;
+void chq_ctx_last_stats(const chq_ctx* ctx, chq_call_stats* out);
+
+int chq_abi_version(void);
+const char* chq_status_name(chq_status s);
+
+/* ---- expressions: sqlparser::ast::Expr ------------------------------------------------------- */
+typedef struct chq_expr chq_expr;
+
+/* sqlparser::ast::BinaryOperator; arms implemented by RU/compute_value.rs:70-209 plus Minus, which the
+ * reference rejects (compute_value.rs:210-216) and so does this library unless the context option
+ * "enable_minus" is set. Any other operator: CHQ_BINOP_OTHER. */
+typedef enum chq_binary_operator {
+  CHQ_BINOP_AND = 0, CHQ_BINOP_OR, CHQ_BINOP_PLUS, CHQ_BINOP_MINUS, CHQ_BINOP_MULTIPLY, CHQ_BINOP_DIVIDE,
+  CHQ_BINOP_MODULO, CHQ_BINOP_EQ, CHQ_BINOP_NOTEQ, CHQ_BINOP_GT, CHQ_BINOP_GTEQ, CHQ_BINOP_LT, CHQ_BINOP_LTEQ,
+  CHQ_BINOP_OTHER
+} chq_binary_operator;
+
+chq_expr* chq_expr_identifier(const char* name);                              /* Expr::Identifier */
+chq_expr* chq_expr_compound_identifier(const char* const* parts, int n);      /* Expr::CompoundIdentifier */
+chq_expr* chq_expr_number(const char* text, int is_long);                     /* Expr::Value(Value::Number(text, long)) */
+chq_expr* chq_expr_boolean(int value);                                        /* Value::Boolean */
+chq_expr* chq_expr_single_quoted_string(const char* bytes, int64_t len);      /* Value::SingleQuotedString */
+chq_expr* chq_expr_unsupported_value(const char* debug);                      /* any other Value */
+/* Expr::BinaryOp { left, op, right }; takes ownership of both children. `op_debug` is the operator's
+ * Debug text, used in the BinaryOperatorNotImplemented message. */
+chq_expr* chq_expr_binary_op(chq_expr* left, chq_binary_operator op, const char* op_debug, chq_expr* right);
+chq_expr* chq_expr_nested(chq_expr* inner);                                   /* Expr::Nested; takes ownership */
+chq_expr* chq_expr_unsupported(const char* debug);                            /* any other Expr variant */
+void chq_expr_free(chq_expr* e);
+
+/* sqlparser::ast::SelectItem, RU/record_projection.rs:25-69 */
+typedef enum chq_select_item_kind {
+  CHQ_ITEM_WILDCARD = 0, CHQ_ITEM_QUALIFIED_WILDCARD, CHQ_ITEM_UNNAMED_EXPR, CHQ_ITEM_EXPR_WITH_ALIAS
+} chq_select_item_kind;
+typedef struct chq_select_item {
+  int kind;               /* chq_select_item_kind */
+  const chq_expr* expr;   /* UNNAMED_EXPR / EXPR_WITH_ALIAS */
+  const char* alias;      /* EXPR_WITH_ALIAS */
+} chq_select_item;
+
+/* table_aliases: &Vec<Vec<String>> -- one alias list per column (RU/record_aliases.rs:12-59).
+ * `n_columns` may be smaller than the batch's column count (the reference's tests pass vec![]). */
+typedef struct chq_alias_list { const char* const* aliases; int n; } chq_alias_list;
+typedef struct chq_table_aliases { const chq_alias_list* columns; int n_columns; } chq_table_aliases;
+
+/* ---- the path -------------------------------------------------------------------------------- */
+/* `out_device`: ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM. On success *out / *out_schema are filled and
+ * must be released by the caller; on failure they are left released (release == NULL). */
+
+/* RU/filter_record.rs:21-39: evaluate `expr` to a BooleanArray, keep the rows where it is true and
+ * valid, every column, original order, same schema; possibly zero rows. */
+chq_status chq_filter_record(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                             const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
+                             struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
+/* RU/record_projection.rs:16-76 */
+chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n_fields,
+                              const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                              const chq_table_aliases* table_aliases, int out_device,
+                              struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
+/* RU/compute_value.rs:57-344: returns ArrayDatum { array, is_scalar } */
+chq_status chq_compute_value(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                             const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
+                             struct ArrowDeviceArray* out, struct ArrowSchema* out_schema, int* out_is_scalar);
+
+/* filter_record followed by project_record on the surviving rows -- the reference's
+ * filter -> exchange -> materialize sequence (filter_task.rs:99, materialize_files_task.rs:110) fused
+ * into one call so the filtered batch never leaves the GPU. */
+chq_status chq_filter_project_record(chq_ctx* ctx, const chq_expr* predicate, const chq_select_item* fields,
+                                     int n_fields, const struct ArrowDeviceArray* rec,
+                                     const struct ArrowSchema* schema, const chq_table_aliases* table_aliases,
+                                     int out_device, struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
+/* ---- device residency helpers ----------------------------------------------------------------- */
+/* Copy a host batch into HBM / a device batch back to host memory. */
+chq_status chq_record_to_device(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                                struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+chq_status chq_record_to_host(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                              struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
+/* Wrap caller-owned device (or host) buffers as a record batch without copying; the buffers must
+ * outlive the returned structs, whose release callbacks free only the descriptors. `format` is an
+ * Arrow C format string ("i","f","g","l","b","u", ...). */
+typedef struct chq_column_desc {
+  const char* name;
+  const char* format;
+  int nullable;
+  int64_t null_count;
+  int64_t offset;          /* logical offset in elements (Arrow slice offset) */
+  const void* validity;    /* NULL when null_count == 0 */
+  const void* values;      /* fixed width: values; bool: bitmap; utf8: int32 offsets */
+  const void* data;        /* utf8: bytes */
+} chq_column_desc;
+chq_status chq_wrap_columns(chq_ctx* ctx, const chq_column_desc* cols, int n_cols, int64_t n_rows, int device_type,
+                            struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHQ_H */
