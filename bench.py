@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X filter path (BASELINE.json / SURVEY.md section 8 d, config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One *step* = one `filter_record` call (`SELECT * WHERE value2 > 10.0`) over ONE device-resident record batch of
+`--rows` rows (default 1e9) with three non-null Float32 columns U[0,100), through the C ABI (libchq.so): predicate
+evaluation + order-preserving compaction of all three columns into freshly allocated HBM buffers, including the
+read-back of the output row count (the Arrow length the caller needs).  Inputs are in HBM before the timed region.
+
+N > 1: one operator instance per GPU (one process per GPU), each filtering its own `--rows`-row shard of an
+N x rows table -- batches are independent in the reference (filter_task.rs:86-125), so there is no data-path
+collective; ranks only all-reduce the elapsed time (MAX) and row counts (SUM) after the timed region ("weak").
+
+Prints ONE JSON line on rank 0 with the driver's fields plus `roofline` (dominant kernel vs HBM peak) and
+`cpu_baseline` (the C oracle = CPU restatement of the reference path, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+PREDICATE = "value2 > 10.0"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    ap.add_argument("--predicate", default=PREDICATE)
+    ap.add_argument("--cpu-rows", type=int, default=200_000_000, help="rows of the same data timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--validate-rows", type=int, default=4_000_000, help="prefix checked bit-exact against the oracle")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the filter path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import chapterhouseqe_amd as chq
+    from chapterhouseqe_amd.sqlparse import parse_expr
+
+    n = args.rows
+    dev = torch.device("cuda", local_rank)
+    # synthetic data: schema value0,value1,value2 : Float32, i.i.d. U[0,100) (create_sample_data.rs:184-189),
+    # counter-based generator seeded 0xC0FFEE + column (+ rank: every GPU holds a different shard)
+    cols = []
+    for c in range(3):
+        g = torch.Generator(device=dev)
+        g.manual_seed(0xC0FFEE + c + 1000 * rank)
+        t = torch.empty(n, dtype=torch.float32, device=dev)
+        t.uniform_(0.0, 100.0, generator=g)
+        cols.append(t)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = chq.Context(local_rank, stream=stream)
+    ctx.set_option("time_kernels", 1)
+    rec = chq.DeviceRecordBatch.from_device_pointers(
+        [(f"value{c}", "f", cols[c].data_ptr()) for c in range(3)], n, ctx=ctx, keepalive=cols)
+    expr = parse_expr(args.predicate)
+    aliases = chq.get_record_table_aliases(None, rec)
+
+    import pyarrow as pa
+    host_schema = pa.schema([pa.field(f"value{c}", pa.float32(), nullable=False) for c in range(3)])
+
+    def step():
+        out = chq.filter_record(rec, aliases, expr, ctx=ctx)   # result stays in HBM
+        st = ctx.last_stats()
+        out.release()
+        return st
+
+    # ---- validation of the timed configuration against the oracle on a prefix ---------------------------
+    validated = None
+    if rank == 0 and args.validate_rows > 0:
+        import numpy as np
+        import pyarrow as pa
+        from oracle import oracle as O
+        from tests.helpers import batches_identical
+        m = min(n, args.validate_rows)
+        host = pa.RecordBatch.from_arrays([pa.array(cols[c][:m].cpu().numpy()) for c in range(3)], schema=host_schema)
+        exp = O.filter_record(host, aliases, expr)
+        sub = chq.DeviceRecordBatch.from_device_pointers([(f"value{c}", "f", cols[c].data_ptr()) for c in range(3)], m, ctx=ctx)
+        got = chq.filter_record(sub, aliases, expr, ctx=ctx)
+        got_h = got.to_host()
+        validated = bool(batches_identical(got_h, exp))
+        got.release()
+        if not validated:
+            raise SystemExit("bench: GPU result differs from the oracle on the validation prefix")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ns = 0
+    stats = None
+    for _ in range(args.steps):
+        stats = step()
+        kernel_ns += stats["kernel_ns"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    rows_out = stats["rows_out"]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([rows_out, kernel_ns], dtype=torch.int64, device=dev)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rows_out_total = int(rr[0].item())
+        kernel_ns = int(rr[1].item()) // world
+    else:
+        rows_out_total = rows_out
+
+    if rank == 0:
+        total_rows = n * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rows * args.steps / elapsed
+        # algorithmic bytes of ONE launch of the dominant kernel (filter_fused_kernel) on one GPU:
+        # 12 B/row read once + 12 B per surviving row written (SURVEY.md section 8 d)
+        alg_bytes = stats["bytes_read_alg"] + stats["bytes_written_alg"]
+        kern_ms = kernel_ns / args.steps / 1e6
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
+        out = {
+            "metric": "filtered rows/sec (input rows), SELECT * WHERE value2 > 10.0, 3 x f32, device-resident",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config 2: SELECT * WHERE {args.predicate} over one {n}-row record batch per GPU, "
+                                   "3 x Float32 U[0,100), non-null, inputs and outputs in HBM",
+                       "rows_per_gpu": n, "selectivity": rows_out / n, "parallelism": f"1 operator instance per GPU x {world}",
+                       "rows_out_total": rows_out_total, "validated_vs_oracle_rows": args.validate_rows if validated else 0},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "kernel": "filter_fused_kernel<1024,16>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "read_frac_of_peak": (stats["bytes_read_alg"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_ms > 0 else None},
+        }
+        if not args.no_cpu_baseline:
+            import pyarrow as pa
+            from oracle import oracle as O
+            m = min(n, args.cpu_rows)
+            host = pa.RecordBatch.from_arrays([pa.array(cols[c][:m].cpu().numpy()) for c in range(3)], schema=host_schema)
+            kept, secs = O.filter_table_batched(host, aliases, expr, batch_rows=10_000)
+            out["cpu_baseline"] = {"value": m / secs, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {m} rows of the same columns, 10 000-row batches, one thread = one "
+                                             f"operator instance (filter_task.rs:86-125), {secs:.1f} s, kept {kept} rows",
+                                   "host_cpus": os.cpu_count()}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

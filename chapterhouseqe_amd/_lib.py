@@ -61,7 +61,7 @@ class ColumnDesc(C.Structure):
 
 class CallStats(C.Structure):
     _fields_ = [("rows_in", C.c_int64), ("rows_out", C.c_int64), ("tiles", C.c_int64), ("launches", C.c_int64),
-                ("bytes_read_alg", C.c_int64), ("bytes_written_alg", C.c_int64)]
+                ("bytes_read_alg", C.c_int64), ("bytes_written_alg", C.c_int64), ("kernel_ns", C.c_int64)]
 
 
 # every symbol include/chq.h declares (checked by tests/test_abi.py)

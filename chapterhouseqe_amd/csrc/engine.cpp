@@ -84,6 +84,8 @@ BufferPtr make_host_buffer(size_t bytes) {
 }
 
 Context::~Context() {
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
   if (pinned) (void)hipHostFree(pinned);
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -500,6 +502,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   const int grid = (int)std::min<int64_t>(ntiles, grid_cap);
   size_t next_fixed = 0;
   bool first = true;
+  if (ctx.opt_time_kernels && !ctx.ev0) { check_hip(hipEventCreate(&ctx.ev0), "hipEventCreate"); check_hip(hipEventCreate(&ctx.ev1), "hipEventCreate"); }
   do {
     FilterParams p{};
     p.nrows = mask_len;
@@ -525,7 +528,9 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     check_hip(hipMemsetAsync(ds, 0, 16, ctx.stream), "memset scratch");
     if (first) check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
     const int kind = first ? tile_kind : (tile_kind == 2 ? 1 : tile_kind);
+    if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev0, ctx.stream), "hipEventRecord");
     check_hip(launch_filter(p, kind, grid, ctx.stream), "launch filter_fused_kernel");
+    if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev1, ctx.stream), "hipEventRecord");
     ++ctx.stats.launches;
     first = false;
   } while (next_fixed < fixed_cols.size());
@@ -533,6 +538,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   Scratch* hs = (Scratch*)ctx.pinned;
   check_hip(hipMemcpyAsync(hs, ds, 32, hipMemcpyDeviceToHost, ctx.stream), "read back");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
   if (hs->err != ERR_NONE) throw_device_error(hs->err);
   const int64_t total = (int64_t)hs->total;
   out.nrows = total;

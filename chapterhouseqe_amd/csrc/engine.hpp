@@ -92,6 +92,8 @@ struct Context {
   // options
   int64_t opt_tile_kind = -1;       // -1 auto
   bool opt_enable_minus = false;
+  bool opt_time_kernels = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // reusable device scratch
   BufferPtr status, byte_status, small;   // small: ticket(4) pad total(8) err(8) total_bytes(8) counters...
   void* pinned = nullptr;                  // pinned host staging for small read-backs (256 B)

@@ -84,12 +84,15 @@ void chq_ctx_destroy(chq_ctx* ctx);
 const char* chq_ctx_last_error(const chq_ctx* ctx);
 /* hipStream_t the context launches on. */
 void* chq_ctx_stream(const chq_ctx* ctx);
-/* Tuning knobs: "tile_rows" (0 = auto), "keep_selection_mask". Unknown keys fail. */
+/* Options: "tile_kind" (-1 auto, 0: 16384-row tiles, 1/2: 2048-row tiles), "enable_minus",
+ * "time_kernels", "trim_pool". Unknown keys fail. */
 chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value);
 /* Counters of the last filter call: rows in, rows out, tiles, kernel launches. */
 typedef struct chq_call_stats {
   int64_t rows_in, rows_out, tiles, launches;
   int64_t bytes_read_alg, bytes_written_alg;   /* algorithmic bytes per SURVEY.md section 8(d) */
+  int64_t kernel_ns;   /* duration of the main kernel launch(es), HIP events on the context's stream; 0 unless
+                          the context option "time_kernels" is set */
 } chq_call_stats;
 void chq_ctx_last_stats(const chq_ctx* ctx, chq_call_stats* out);
 
