@@ -87,6 +87,27 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; a process that loads both that
+    copy and /opt/rocm's ends up with two HSA runtimes and the second one sees no GPU.  When torch is installed,
+    bind to the runtime it ships (without importing torch) so both share one, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -95,6 +116,7 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C chapterhouseqe_amd/csrc). There is no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i64, cp, ci = C.c_void_p, C.c_int64, C.c_char_p, C.c_int
     PDA, PS = C.POINTER(ArrowDeviceArray), C.POINTER(ArrowSchema)

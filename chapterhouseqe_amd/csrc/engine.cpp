@@ -420,6 +420,26 @@ int pick_tile_kind(const Context& ctx, const Lowered& lw, int64_t rows) {
   return rows >= (1 << 18) ? 0 : 1;
 }
 
+std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols,
+                                   const std::vector<const TypedExpr*>& exprs);
+
+// type_expr + the reference's error order: data-dependent errors of subtrees evaluated before a static
+// error take precedence over it
+TypedExpr typed(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr) {
+  TypedExpr te = type_expr(expr, pcols, rec.nrows, ctx.opt_enable_minus);
+  if (te.pending_code) {
+    if (rec.nrows > 0) {
+      std::vector<TypedExpr> subs;
+      for (int r : te.validate_roots) { TypedExpr s; s.nodes = te.nodes; s.root = r; subs.push_back(std::move(s)); }
+      std::vector<const TypedExpr*> ptrs;
+      for (auto& s : subs) ptrs.push_back(&s);
+      (void)evaluate_dense(ctx, rec, pcols, ptrs);   // throws the data-dependent error if there is one
+    }
+    throw ChqError{te.pending_code, te.pending_msg};
+  }
+  return te;
+}
+
 Column empty_like(const Column& c) {
   Column o;
   o.name = c.name; o.format = c.format; o.type = c.type; o.width = c.width; o.nullable = c.nullable;
@@ -433,10 +453,13 @@ Column empty_like(const Column& c) {
 // =================================================================================================
 Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr) {
   const int64_t nrows = rec.nrows;
-  TypedExpr te = type_expr(expr, pcols, nrows, ctx.opt_enable_minus);
+  TypedExpr te = typed(ctx, rec, pcols, expr);
   const Node& root = te.at(te.root);
-  if (root.type != T_BOOL)   // RU/filter_record.rs:27-35
+  if (root.type != T_BOOL) {   // RU/filter_record.rs:27-35
+    // the reference has already evaluated the expression at this point: data-dependent errors come first
+    if (root.kind != Node::COL && !root.len1 && nrows > 0) { std::vector<const TypedExpr*> v{&te}; (void)evaluate_dense(ctx, rec, pcols, v); }
     throw ChqError{CHQ_ERR_CAST_TO_BOOLEAN_ARRAY_FAILED, std::string("cast to boolean array failed for array type: ") + dtype_name(root.type)};
+  }
   // A literal-only predicate is a length-1 mask: arrow filters just the first row (and rejects a mask
   // longer than the columns) -- reproduced, not "fixed" (SURVEY.md section 8 a8).
   const int64_t mask_len = root.len1 ? 1 : nrows;
@@ -753,9 +776,9 @@ struct Evaluated {
   bool is_scalar = false;
 };
 
-Evaluated classify(const Expr& e, const std::vector<PlanColumn>& pcols, int64_t nrows, bool enable_minus) {
+Evaluated classify(Context& ctx, const Batch& rec, const Expr& e, const std::vector<PlanColumn>& pcols) {
   Evaluated ev;
-  ev.typed = type_expr(e, pcols, nrows, enable_minus);
+  ev.typed = typed(ctx, rec, pcols, e);
   const Node& root = ev.typed.at(ev.typed.root);
   ev.is_scalar = root.is_scalar;
   if (root.kind == Node::COL) { ev.kind = Evaluated::PASSTHROUGH; ev.col = root.col; }
@@ -768,7 +791,7 @@ Evaluated classify(const Expr& e, const std::vector<PlanColumn>& pcols, int64_t 
 
 Column compute_value(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr, bool* is_scalar) {
   ctx.stats = chq_call_stats{};
-  Evaluated ev = classify(expr, pcols, rec.nrows, ctx.opt_enable_minus);
+  Evaluated ev = classify(ctx, rec, expr, pcols);
   if (is_scalar) *is_scalar = ev.is_scalar;
   Column out;
   switch (ev.kind) {
@@ -794,12 +817,28 @@ Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, c
         for (const Column& c : rec.cols) out.cols.push_back(clone_device_column(ctx, c));
         break;
       case CHQ_ITEM_QUALIFIED_WILDCARD:
+        if (!evs.empty()) {
+          std::vector<const TypedExpr*> ptrs;
+          for (auto& p : evs) ptrs.push_back(&p.typed);
+          (void)evaluate_dense(ctx, rec, pcols, ptrs);
+        }
         throw ChqError{CHQ_ERR_PROJECT_NOT_IMPLEMENTED, "not implemented: SelectItem::QualifiedWildcard"};
       case CHQ_ITEM_UNNAMED_EXPR:
       case CHQ_ITEM_EXPR_WITH_ALIAS: {
         if (!f.expr) throw ChqError{CHQ_ERR_INVALID_HANDLE, "select item without expression"};
         const Expr& e = *(const Expr*)f.expr;
-        Evaluated ev = classify(e, pcols, rec.nrows, ctx.opt_enable_minus);
+        Evaluated ev;
+        try {
+          ev = classify(ctx, rec, e, pcols);
+        } catch (const ChqError&) {
+          // the reference evaluates the items in order: errors of earlier computed items come first
+          if (!evs.empty()) {
+            std::vector<const TypedExpr*> ptrs;
+            for (auto& p : evs) ptrs.push_back(&p.typed);
+            (void)evaluate_dense(ctx, rec, pcols, ptrs);
+          }
+          throw;
+        }
         std::string name;
         if (f.kind == CHQ_ITEM_EXPR_WITH_ALIAS) name = f.alias ? f.alias : "";
         else if (e.kind == Expr::IDENT) name = e.text;                 // RU/record_projection.rs:41-48

@@ -365,10 +365,27 @@ struct Typer {
 };
 }  // namespace
 
+static bool has_checked_arith(const TypedExpr& t, int ni) {
+  const Node& n = t.at(ni);
+  if (n.kind == Node::ARITH && is_int(n.type) && !n.len1) return true;
+  return (n.l >= 0 && has_checked_arith(t, n.l)) || (n.r >= 0 && has_checked_arith(t, n.r));
+}
+
 TypedExpr type_expr(const Expr& e, const std::vector<PlanColumn>& cols, int64_t nrows, bool enable_minus) {
   Typer ty{cols, nrows, enable_minus, {}, 0};
-  int root = ty.build(e);
-  ty.t.root = root;
+  try {
+    int root = ty.build(e);
+    ty.t.root = root;
+  } catch (const ChqError& err) {
+    // completed subtrees = nodes nobody points at; keep those that can fail on data, in evaluation order
+    std::vector<char> is_child(ty.t.nodes.size(), 0);
+    for (const Node& n : ty.t.nodes) { if (n.l >= 0) is_child[n.l] = 1; if (n.r >= 0) is_child[n.r] = 1; }
+    std::vector<int> roots;
+    for (size_t i = 0; i < ty.t.nodes.size(); ++i)
+      if (!is_child[i] && has_checked_arith(ty.t, (int)i)) roots.push_back((int)i);
+    if (roots.empty()) throw;
+    ty.t.pending_code = err.code; ty.t.pending_msg = err.msg; ty.t.validate_roots = roots; ty.t.root = -1;
+  }
   return std::move(ty.t);
 }
 

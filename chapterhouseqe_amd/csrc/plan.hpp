@@ -67,11 +67,17 @@ struct Node {
 struct TypedExpr {
   std::vector<Node> nodes;
   int root = -1;
+  // A static error (type / lookup / literal-folding error) met while walking the tree.  The reference would
+  // already have evaluated every subtree completed before that point, so a data-dependent error (integer
+  // overflow, division by zero) in one of `validate_roots` wins over it; the engine checks them first.
+  int pending_code = 0;
+  std::string pending_msg;
+  std::vector<int> validate_roots;
   const Node& at(int i) const { return nodes[i]; }
 };
 
-// Build the typed tree for `e` against the batch columns; throws ChqError exactly where the reference
-// returns Err (static errors).  `nrows` is needed for the arrow length rules between len-1 arrays and
+// Build the typed tree for `e` against the batch columns.  A static error is thrown directly when nothing
+// evaluated before it could have failed on data; otherwise it is returned as `pending_*` (see TypedExpr).  `nrows` is needed for the arrow length rules between len-1 arrays and
 // columns.  `enable_minus`: accept BinaryOperator::Minus (not implemented by the reference).
 TypedExpr type_expr(const Expr& e, const std::vector<PlanColumn>& cols, int64_t nrows, bool enable_minus);
 

@@ -43,7 +43,12 @@ class Context:
     """One per operator instance (the reference processes one batch at a time per instance)."""
 
     def __init__(self, device_id: int = 0, stream: Optional[int] = None):
+        """`stream`: a hipStream_t handle to launch on (e.g. torch.cuda.current_stream().cuda_stream); 0 means the
+        legacy default stream (passed to the C ABI as hipStreamLegacy); None lets the context create its own
+        non-blocking stream (work issued on other streams must then be synchronised by the caller)."""
         self._h = C.c_void_p()
+        if stream is not None and stream == 0:
+            stream = 1   # hipStreamLegacy
         rc = L.lib().chq_ctx_create(device_id, C.c_void_p(stream) if stream else None, C.byref(self._h))
         if rc:
             raise ChqError(rc, f"chq_ctx_create(device {device_id}) failed: no usable MI355X/HIP device")

@@ -1,0 +1,44 @@
+"""Seeded regeneration of the reference's sample data sets and its sample queries.
+
+The reference writes its samples with an UNSEEDED `rand::thread_rng` (src/bin/create_sample_data.rs:172-189), so
+there is no canonical file to compare against; this module reproduces the schema and the distributions
+(id: Int32 = 0..size-1, value1: Utf8 of `string_size` chars uniform in 'a'..='z', value2: Float32 ~ U[0,100);
+all non-null; cut into `rows_per_file`-row files, create_sample_data.rs:113-155) from a fixed seed.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import numpy as np
+import pyarrow as pa
+
+# reference: sample_queries/simple.sql (text reproduced: it is the workload definition of BASELINE config 1)
+SIMPLE_SQL = """
+select * from read_files('sample_data/simple/*.parquet') where id < 25;
+select * from read_files('sample_data/simple_wide_string/*.parquet') where id > 25;
+select id, value2 from read_files('sample_data/simple/*.parquet') where id < 75;
+select id, value1, id + 10.0 as id_plus_10, (value2 + 10) / 100 as value2, 1.0 / id as value3,
+       1.0 / (id * id) as value4, id * id as value5
+  from read_files('sample_data/simple/*.parquet') where id > 25 + 0.0;
+select * from read_files('sample_data/simple/*.parquet') where id % 2 = 0;
+"""
+
+SCHEMA = pa.schema([pa.field("id", pa.int32(), False), pa.field("value1", pa.utf8(), False),
+                    pa.field("value2", pa.float32(), False)])
+
+
+def simple_table(size: int, string_size: int, seed: int = 0xC0FFEE) -> pa.RecordBatch:
+    rng = np.random.default_rng(seed)
+    ids = np.arange(size, dtype=np.int32)
+    chars = rng.integers(ord("a"), ord("z") + 1, size=size * string_size, dtype=np.uint8)
+    offsets = (np.arange(size + 1, dtype=np.int64) * string_size).astype(np.int32)
+    value1 = pa.Array.from_buffers(pa.utf8(), size, [None, pa.py_buffer(offsets.tobytes()), pa.py_buffer(chars.tobytes())])
+    value2 = (rng.random(size) * 100.0).astype(np.float32)
+    return pa.RecordBatch.from_arrays([pa.array(ids), value1, pa.array(value2)], schema=SCHEMA)
+
+
+def simple_batches(size: int = 100, string_size: int = 8, rows_per_file: int = 33, seed: int = 0xC0FFEE) -> List[pa.RecordBatch]:
+    """simple: (100, 8, 33); simple_wide_string: (100, 100, 33); large_simple: (10_000, 8, 1000);
+    huge_simple: (1_000_000, 8, 10_000) -- create_sample_data.rs:113-155."""
+    table = simple_table(size, string_size, seed)
+    return [table.slice(s, min(rows_per_file, size - s)) for s in range(0, size, rows_per_file)]

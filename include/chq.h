@@ -76,8 +76,9 @@ typedef enum chq_status {
 /* ---- context -------------------------------------------------------------------------------- */
 typedef struct chq_ctx chq_ctx;
 
-/* One context per operator instance.  `hip_stream` is a hipStream_t to run on, or NULL to let the
- * context create its own non-blocking stream.  Fails with CHQ_ERR_DEVICE when no GPU is usable. */
+/* One context per operator instance.  `hip_stream` is a hipStream_t to run on (pass hipStreamLegacy /
+ * hipStreamPerThread for the default streams), or NULL to let the context create its own non-blocking
+ * stream -- in that case work the caller issued on other streams must be synchronised by the caller.  Fails with CHQ_ERR_DEVICE when no GPU is usable. */
 chq_status chq_ctx_create(int device_id, void* hip_stream, chq_ctx** out);
 void chq_ctx_destroy(chq_ctx* ctx);
 /* Message of the last failing call on this context (valid until the next call on it). */

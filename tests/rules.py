@@ -1,0 +1,163 @@
+"""Hand-derived expectations for the arrow-rs 53 semantics the reference relies on but does not pin with
+its own tests ("unpinned-by-reference").  Every expected value below was
+worked out from the documented behaviour, NOT produced by the oracle or the GPU library; both are tested
+against this table (tests/test_oracle_golden.py on CPU, tests/test_gpu_parity.py on the GPU).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pyarrow as pa
+
+NAN = float("nan")
+INF = float("inf")
+
+
+def _f32(vals, mask=None):
+    return pa.array(np.array(vals, dtype=np.float32), mask=None if mask is None else np.array(mask))
+
+
+def _neg_nan32():
+    return np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]
+
+
+def batch_floats():
+    x = np.array([-0.0, 0.0, NAN, INF, -INF, 1.5], dtype=np.float32)
+    x = np.concatenate([x, np.array([_neg_nan32()], dtype=np.float32)])
+    y = np.array([0.0, -0.0, NAN, INF, 0.0, 1.5, NAN], dtype=np.float32)
+    return pa.RecordBatch.from_arrays([pa.array(x), pa.array(y), pa.array(x.astype(np.float64))], names=["x", "y", "d"])
+
+
+def batch_ints():
+    return pa.RecordBatch.from_arrays([
+        pa.array([1, -7, 2147483647, -2147483648, 0, 9], pa.int32()),
+        pa.array([3, 2, 1, -1, 5, 0], pa.int32()),
+        pa.array([100, 200, 255, 0, 1, 2], pa.uint8()),
+        pa.array([1, 2, 3, 4, 5, 6], pa.int64()),
+        pa.array([1, 2, 3, 4, 5, 6], pa.uint32()),
+        pa.array([-128, 127, 5, -5, 0, 1], pa.int8()),
+    ], names=["i", "j", "u8", "l", "u32", "i8"])
+
+
+def batch_nulls():
+    return pa.RecordBatch.from_arrays([
+        pa.array([1, None, 3, 4, None, 6], pa.int32()),
+        pa.array([10, 20, None, 40, None, 0], pa.int32()),
+        pa.array([True, None, False, True, None, False], pa.bool_()),
+        pa.array(["a", None, "c", "dd", "e", None], pa.utf8()),
+        pa.array([1.5, 2.5, None, None, 5.5, 6.5], pa.float32()),
+    ], names=["a", "b", "t", "s", "f"])
+
+
+def batch_strings():
+    return pa.RecordBatch.from_arrays([
+        pa.array(["b", "a", "", "ab", "abc", "bé", "B"], pa.utf8()),
+        pa.array(["b", "b", "b", "aa", "ab", "b", "b"], pa.utf8()),
+        pa.array([0, 1, 2, 3, 4, 5, 6], pa.int32()),
+    ], names=["s", "r", "id"])
+
+
+# (name, batch factory, kind, sql / select, expectation)
+# kind "value": expectation = (arrow type, python list)   [compute_value]
+# kind "filter": expectation = list of surviving row indices of the input batch
+# kind "error": expectation = status code
+# kind "project": expectation = dict name -> (type, values) in output order, plus "nullable" dict
+RULES = [
+    # ---- IEEE totalOrder comparisons (arrow-ord cmp; ArrowNativeTypeOp::compare = total_cmp) -----------------
+    ("float_lt_zero_total_order", batch_floats, "value", "x < 0.0", (pa.bool_(), [True, False, False, False, True, False, True])),
+    ("float_eq_is_bitwise", batch_floats, "value", "x = y", (pa.bool_(), [False, False, True, True, False, True, False])),
+    ("float_neq_is_bitwise", batch_floats, "value", "x <> y", (pa.bool_(), [True, True, False, False, True, False, True])),
+    ("float_gt_nan_is_greatest", batch_floats, "value", "x > 1000000.0", (pa.bool_(), [False, False, True, True, False, False, False])),
+    ("float_lteq_total_order", batch_floats, "value", "x <= y", (pa.bool_(), [True, False, True, True, True, True, True])),
+    ("float_gteq_total_order", batch_floats, "value", "x >= y", (pa.bool_(), [False, True, True, True, False, True, False])),
+    ("float64_total_order", batch_floats, "value", "d < 0.0", (pa.bool_(), [True, False, False, False, True, False, True])),
+    # ---- float arithmetic is plain IEEE --------------------------------------------------------------------
+    ("float_div_by_zero", batch_floats, "value", "x / 0.0", (pa.float32(), [NAN, NAN, NAN, INF, -INF, INF, NAN])),
+    ("float_rem_is_fmod", batch_ints, "value", "i % 2.5", (pa.float32(), [1.0, -2.0, math.fmod(2147483648.0, 2.5), -math.fmod(2147483648.0, 2.5), 0.0, 1.5])),
+    # ---- checked integer arithmetic ------------------------------------------------------------------------
+    ("int_add_overflow_errors", batch_ints, "error", "i + 1", 20),
+    ("int_mul_overflow_errors", batch_ints, "error", "i * 2", 20),
+    ("int_div_by_zero_errors", batch_ints, "error", "u8 / (u8 % 2)", 21),
+    ("int64_div_by_zero_errors", batch_ints, "error", "l / (l % 2)", 21),
+    ("int_rem_by_zero_errors", batch_ints, "error", "j % (j % 1)", 21),
+    ("first_offending_row_decides_the_error", batch_ints, "error", "i / j", 20),
+    ("int_div_truncates", batch_ints, "value", "i / 2", (pa.int32(), [0, -3, 1073741823, -1073741824, 0, 4])),
+    ("int_rem_sign_of_dividend", batch_ints, "value", "i % 4", (pa.int32(), [1, -3, 3, 0, 0, 1])),
+    ("uint8_add_checked", batch_ints, "error", "u8 + u8", 20),
+    ("int8_mul_checked", batch_ints, "error", "i8 * i8", 20),
+    ("widening_u8_to_i32", batch_ints, "value", "u8 + 1000", (pa.int32(), [1100, 1200, 1255, 1000, 1001, 1002])),
+    ("widening_i32_to_i64", batch_ints, "value", "j * l", (pa.int64(), [3, 4, 3, -4, 25, 0])),
+    ("i32_big_literal_is_i64", batch_ints, "value", "j + 3000000000", (pa.int64(), [3000000003, 3000000002, 3000000001, 2999999999, 3000000005, 3000000000])),
+    ("int_to_f32_coercion", batch_ints, "value", "j / 2.0", (pa.float32(), [1.5, 1.0, 0.5, -0.5, 2.5, 0.0])),
+    ("constant_subexpression_stays_scalar", batch_ints, "filter", "i > 25 + 0.0", [2]),
+    # ---- coercion table misses -----------------------------------------------------------------------------
+    ("i64_with_f32_unsupported", batch_ints, "error", "l + 1.5", 9),
+    ("u32_with_i32_unsupported", batch_ints, "error", "u32 + 1", 9),
+    ("bool_with_int_unsupported", batch_nulls, "error", "t = 1", 9),
+    ("utf8_with_int_unsupported", batch_strings, "error", "s = 1", 9),
+    ("utf8_arithmetic_invalid", batch_strings, "error", "s + r", 22),
+    ("minus_not_implemented", batch_ints, "error", "i - 1", 3),
+    ("unary_minus_not_implemented", batch_ints, "error", "i > -5", 2),
+    ("column_not_found", batch_ints, "error", "nope > 1", 7),
+    ("compound_identifier_not_found", batch_ints, "error", "t.i > 1", 8),
+    ("three_part_identifier_not_found", batch_ints, "error", "a.b.c > 1", 8),
+    ("long_number_not_implemented", batch_ints, "error", "i > 5L", 1),
+    ("null_literal_not_implemented", batch_ints, "error", "i = null", 1),
+    ("filter_needs_boolean", batch_ints, "error_filter", "i + 1000000000000", 10),
+    # ---- nulls: non-Kleene and/or, union of validities, null mask slot = dropped ----------------------------
+    ("null_propagates_through_add", batch_nulls, "value", "a + b", (pa.int32(), [11, None, None, 44, None, 6])),
+    ("null_propagates_through_cmp", batch_nulls, "value", "a < b", (pa.bool_(), [True, None, None, True, None, False])),
+    ("and_is_not_kleene", batch_nulls, "value", "t and a > 100", (pa.bool_(), [False, None, False, False, None, False])),
+    ("or_is_not_kleene", batch_nulls, "value", "t or a > 0", (pa.bool_(), [True, None, True, True, None, True])),
+    ("null_mask_rows_are_dropped", batch_nulls, "filter", "a < b", [0, 3]),
+    ("null_div_zero_slot_is_not_an_error", batch_nulls, "value", "b / a", (pa.int32(), [10, None, None, 10, None, 0])),
+    ("int_and_casts_to_bool", batch_nulls, "value", "a and b", (pa.bool_(), [True, None, None, True, None, False])),
+    ("float_and_casts_to_bool", batch_nulls, "filter", "f and t", [0]),
+    ("utf8_eq_with_nulls", batch_nulls, "value", "s = 'c'", (pa.bool_(), [False, None, True, False, False, None])),
+    ("filter_keeps_nulls_in_other_columns", batch_nulls, "filter", "f > 2.0", [1, 4, 5]),
+    # ---- Utf8 comparisons are byte-lexicographic -------------------------------------------------------------
+    ("utf8_lt_scalar", batch_strings, "value", "s < 'b'", (pa.bool_(), [False, True, True, True, True, False, True])),
+    ("utf8_gteq_scalar", batch_strings, "value", "s >= 'ab'", (pa.bool_(), [True, False, False, True, True, True, False])),
+    ("utf8_scalar_on_the_left", batch_strings, "value", "'ab' < s", (pa.bool_(), [True, False, False, False, True, True, False])),
+    ("utf8_column_vs_column", batch_strings, "value", "s <= r", (pa.bool_(), [True, True, True, False, False, False, True])),
+    ("utf8_filter_mixed", batch_strings, "filter", "s <> 'b' and id % 2 = 0", [2, 4, 6]),
+    # ---- and / or take plain BooleanArrays: no scalar broadcast, result is never a scalar ---------------------
+    ("and_with_literal_length_mismatch", batch_ints, "error", "i > 0 and true", 23),
+    ("or_with_literal_length_mismatch", batch_ints, "error", "false or i > 0", 23),
+    ("and_of_literals_is_len1_array", batch_ints, "value", "true and false", (pa.bool_(), [False])),
+    ("len1_array_vs_column_length_mismatch", batch_ints, "error", "(true and true) = (i > 0)", 22),
+    # ---- scalar predicate quirk: a literal-only mask has length 1, arrow filters the first row only ------------
+    ("where_true_keeps_first_row_only", batch_ints, "filter", "true", [0]),
+    ("where_false_keeps_nothing", batch_ints, "filter", "false", []),
+    ("where_constant_comparison", batch_ints, "filter", "1 < 2", [0]),
+]
+
+PROJECT_RULES = [
+    # name, batch factory, select list sql, expected [(name, type, values, nullable)]
+    ("naming_unnamed_counts_identifiers", batch_ints,
+     "select i, j + 1, i8, j * 2, l as big from t",
+     [("i", pa.int32(), [1, -7, 2147483647, -2147483648, 0, 9], False),
+      ("unnamed_1", pa.int32(), [4, 3, 2, 0, 6, 1], False),
+      ("i8", pa.int8(), [-128, 127, 5, -5, 0, 1], False),
+      ("unnamed_3", pa.int32(), [6, 4, 2, -2, 10, 0], False),
+      ("big", pa.int64(), [1, 2, 3, 4, 5, 6], False)]),
+    ("nullable_follows_null_count", batch_nulls,
+     "select a + 1 as a1, f, t and t as tt, s from t",
+     [("a1", pa.int32(), [2, None, 4, 5, None, 7], True),
+      ("f", pa.float32(), [1.5, 2.5, None, None, 5.5, 6.5], True),
+      ("tt", pa.bool_(), [True, None, False, True, None, False], True),
+      ("s", pa.utf8(), ["a", None, "c", "dd", "e", None], True)]),
+    ("wildcard_then_expr", batch_strings,
+     "select *, id * id as sq from t",
+     [("s", pa.utf8(), ["b", "a", "", "ab", "abc", "bé", "B"], True),
+      ("r", pa.utf8(), ["b", "b", "b", "aa", "ab", "b", "b"], True),
+      ("id", pa.int32(), [0, 1, 2, 3, 4, 5, 6], True),
+      ("sq", pa.int32(), [0, 1, 4, 9, 16, 25, 36], False)]),
+]
+
+PROJECT_ERRORS = [
+    ("qualified_wildcard_not_implemented", batch_ints, "select t.* from t", 11),
+    ("scalar_projection_length_mismatch", batch_ints, "select i, 1 + 2 from t", 22),
+    ("projection_error_propagates", batch_ints, "select i * i from t", 20),
+]

@@ -1,0 +1,127 @@
+"""CPU: pin the oracle (a) against every known-answer vector of the reference's own unit tests, (b) against the
+hand-derived arrow-rs semantics table, (c) against pyarrow/numpy where their semantics coincide."""
+import numpy as np
+import pyarrow as pa
+import pyarrow.compute as pc
+import pytest
+
+from chapterhouseqe_amd.sqlparse import parse_expr, parse_select
+from oracle import oracle as O
+
+from . import rules
+from .cases import empty_aliases, run_golden_case, run_project_error, run_project_rule, run_rule
+from .helpers import arrays_identical, load_golden
+
+GOLD = load_golden("reference_cases.json")
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_oracle_matches_reference_test_vectors(case):
+    """pinned-by-reference: record_utils/test_*.rs"""
+    run_golden_case(O, case)
+
+
+def test_every_reference_test_is_accounted_for():
+    # 8 (test_compute_value.rs) + 1 (test_filter_record.rs) + 6 (test_arrow_compute_behavior.rs) = 15
+    assert len(GOLD["cases"]) + len(GOLD["not_on_path"]) == 15
+
+
+@pytest.mark.parametrize("rule", rules.RULES, ids=[r[0] for r in rules.RULES])
+def test_oracle_follows_arrow_semantics(rule):
+    """unpinned-by-reference: documented arrow-rs 53 behaviour"""
+    run_rule(O, rule)
+
+
+@pytest.mark.parametrize("rule", rules.PROJECT_RULES, ids=[r[0] for r in rules.PROJECT_RULES])
+def test_oracle_project_record(rule):
+    run_project_rule(O, rule)
+
+
+@pytest.mark.parametrize("rule", rules.PROJECT_ERRORS, ids=[r[0] for r in rules.PROJECT_ERRORS])
+def test_oracle_project_errors(rule):
+    run_project_error(O, rule)
+
+
+# ---- secondary cross-check: Arrow C++ (pyarrow) / numpy, only where semantics coincide --------
+def _rand_batch(n, seed):
+    rng = np.random.default_rng(seed)
+    return pa.RecordBatch.from_arrays([
+        pa.array(rng.integers(-1000, 1000, n).astype(np.int32)),
+        pa.array(rng.integers(1, 50, n).astype(np.int32)),
+        pa.array((rng.random(n) * 100).astype(np.float32)),
+        pa.array(rng.random(n) * 10 - 5, mask=rng.random(n) < 0.15),
+        pa.array(rng.integers(0, 2, n).astype(bool), mask=rng.random(n) < 0.1),
+        pa.array(["k%d" % v for v in rng.integers(0, 30, n)]),
+    ], names=["a", "b", "x", "d", "t", "s"])
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 10_001])
+def test_oracle_vs_pyarrow_numpy(n):
+    rec = _rand_batch(n, n)
+    al = empty_aliases(rec)
+    a, b, x, d, t, s = (rec.column(i) for i in range(6))
+    checks = [
+        ("a + b", pc.add_checked(a, b)),
+        ("a * b", pc.multiply_checked(a, b)),
+        ("a / b", pc.divide_checked(a, b)),                       # truncating int division
+        ("x * 2.0", pc.multiply(x, pa.scalar(2.0, pa.float32()))),
+        ("x / 3.0", pc.divide(x, pa.scalar(3.0, pa.float32()))),
+        ("a + 1.5", pc.add(pc.cast(a, pa.float32()), pa.scalar(1.5, pa.float32()))),
+        ("d + a", pc.add(d, pc.cast(a, pa.float64()))),
+        ("a < b", pc.less(a, b)),
+        ("a >= 10", pc.greater_equal(a, pa.scalar(10, pa.int32()))),
+        ("x > 50.0", pc.greater(x, pa.scalar(50.0, pa.float32()))),     # no NaN / signed zero in this data
+        ("d <= 0.5", pc.less_equal(d, pa.scalar(0.5, pa.float64()))),
+        ("t and a > 0", pc.and_(t, pc.greater(a, pa.scalar(0, pa.int32())))),   # pc.and_ is the non-Kleene form
+        ("t or d > 0.0", pc.or_(t, pc.greater(d, pa.scalar(0.0, pa.float64())))),
+        ("s = 'k7'", pc.equal(s, pa.scalar("k7"))),
+        ("s < 'k2'", pc.less(s, pa.scalar("k2"))),
+    ]
+    for sql, exp in checks:
+        got, _ = O.compute_value(rec, al, parse_expr(sql))
+        assert arrays_identical(got, exp), sql
+    # C-style remainder via numpy (pyarrow has no modulo kernel)
+    got, _ = O.compute_value(rec, al, parse_expr("a % b"))
+    assert got.to_pylist() == np.fmod(a.to_numpy(), b.to_numpy()).astype(np.int32).tolist()
+    # filter: pc.filter drops rows whose mask slot is null, like arrow-rs
+    mask = pc.and_(t, pc.greater(x, pa.scalar(20.0, pa.float32())))
+    got = O.filter_record(rec, al, parse_expr("t and x > 20.0"))
+    exp = rec.filter(mask, null_selection_behavior="drop")
+    assert got.equals(exp)
+
+
+def test_simple_sql_sample_queries_on_regenerated_dataset():
+    """Config 1 (plumbing): the five statements of the reference's sample_queries/simple.sql run through the
+    reference's operator sequence (filter on the full-width batch, then projection) on a regenerated `simple`
+    data set: id = 0..99, value1 = 8 lowercase chars, value2 ~ U[0,100) (create_sample_data.rs:157-204), cut
+    into 33-row files/batches (create_sample_data.rs:139)."""
+    from chapterhouseqe_amd.sample_data import SIMPLE_SQL, simple_batches
+    batches = simple_batches(size=100, string_size=8, rows_per_file=33, seed=0xC0FFEE)
+    assert [b.num_rows for b in batches] == [33, 33, 33, 1]
+    from chapterhouseqe_amd.sqlparse import parse_statements
+    stmts = parse_statements(SIMPLE_SQL)
+    assert len(stmts) == 5
+    expect_ids = [list(range(0, 25)), None, list(range(0, 75)), list(range(26, 100)), list(range(0, 100, 2))]
+    for q, (sel, ids) in enumerate(zip(stmts, expect_ids)):
+        if ids is None:
+            continue   # query 2 reads the wide-string data set, covered in test_gpu_parity
+        got_ids, outs = [], []
+        for b in batches:
+            al = [[] for _ in range(b.num_columns)]
+            f = O.filter_record(b, al, sel.selection)
+            p = O.project_record(sel.projection, f, al)
+            outs.append(p)
+            got_ids += p.column(0).to_pylist()
+        assert got_ids == ids, f"query {q + 1}"
+        if q == 3:   # query 4: seven projected columns checked against numpy float32
+            allp = pa.Table.from_batches(outs).to_pandas()
+            full = pa.Table.from_batches(batches).to_pandas()
+            full = full[full.id > 25]
+            idf = full.id.to_numpy().astype(np.float32)
+            np.testing.assert_array_equal(allp.id_plus_10.to_numpy(), idf + np.float32(10.0))
+            np.testing.assert_array_equal(allp.value2.to_numpy(), (full.value2.to_numpy() + np.float32(10)) / np.float32(100))
+            np.testing.assert_array_equal(allp.value3.to_numpy(), np.float32(1.0) / idf)
+            idsq = (full.id.to_numpy() * full.id.to_numpy()).astype(np.int32)
+            np.testing.assert_array_equal(allp.value4.to_numpy(), np.float32(1.0) / idsq.astype(np.float32))
+            np.testing.assert_array_equal(allp.value5.to_numpy(), idsq)
+            assert list(allp.columns) == ["id", "value1", "id_plus_10", "value2", "value3", "value4", "value5"]
