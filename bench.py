@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--predicate", default=PREDICATE)
     ap.add_argument("--cpu-rows", type=int, default=200_000_000, help="rows of the same data timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="context option key=value (experiments)")
     ap.add_argument("--validate-rows", type=int, default=4_000_000, help="prefix checked bit-exact against the oracle")
     return ap.parse_args()
 
@@ -77,6 +78,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ctx = chq.Context(local_rank, stream=stream)
     ctx.set_option("time_kernels", 1)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     rec = chq.DeviceRecordBatch.from_device_pointers(
         [(f"value{c}", "f", cols[c].data_ptr()) for c in range(3)], n, ctx=ctx, keepalive=cols)
     expr = parse_expr(args.predicate)

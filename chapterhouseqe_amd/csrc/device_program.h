@@ -105,7 +105,7 @@ struct FilterParams {
   u64* sel_mask;     // optional: selection bitmap (one u64 per 64 rows), for follow-up kernels
   u64* grp_base;     // optional: output row index of each 64-row group's first selected row
   int32_t n_out;
-  int32_t pad;
+  int32_t debug;          // experiments only: bit0 = no inter-tile dependency (base = tile * TILE), bit1 = skip last column
   ProgramBlock pb;
   OutCol outs[MAX_OUT];
 };

@@ -358,7 +358,8 @@ std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* al
 // =================================================================================================
 namespace {
 
-constexpr int64_t kTileRows[3] = {1024 * 16, 256 * 8, 256 * 8};
+constexpr int64_t kTileRows[5] = {1024 * 16, 256 * 8, 256 * 8, 512 * 16, 256 * 16};
+constexpr int kGridPerCu[5] = {1, 4, 4, 2, 4};
 
 struct Scratch {   // layout of ctx.small (device) and ctx.pinned (host mirror)
   uint32_t ticket; uint32_t pad0;
@@ -521,7 +522,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   // predicate inputs that are not output columns cannot occur for filter_record (SELECT * semantics):
   // every referenced column is also copied, so it is counted once above.
 
-  const int grid_cap = tile_kind == 0 ? ctx.num_cus : ctx.num_cus * 4;
+  const int grid_cap = ctx.num_cus * (ctx.opt_grid_per_cu > 0 ? (int)ctx.opt_grid_per_cu : kGridPerCu[tile_kind]);
   const int grid = (int)std::min<int64_t>(ntiles, grid_cap);
   size_t next_fixed = 0;
   bool first = true;
@@ -547,10 +548,11 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       ++n;
     }
     p.n_out = n;
+    p.debug = (int32_t)ctx.opt_debug;
     check_hip(hipMemsetAsync(ctx.status->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset status");
     check_hip(hipMemsetAsync(ds, 0, 16, ctx.stream), "memset scratch");
     if (first) check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
-    const int kind = first ? tile_kind : (tile_kind == 2 ? 1 : tile_kind);
+    const int kind = first ? tile_kind : (tile_kind == 2 ? 1 : tile_kind);   // kinds 1 and 2 share a tile size
     if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev0, ctx.stream), "hipEventRecord");
     check_hip(launch_filter(p, kind, grid, ctx.stream), "launch filter_fused_kernel");
     if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev1, ctx.stream), "hipEventRecord");

@@ -93,6 +93,8 @@ struct Context {
   int64_t opt_tile_kind = -1;       // -1 auto
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
+  int64_t opt_grid_per_cu = 0;
+  int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // reusable device scratch
   BufferPtr status, byte_status, small;   // small: ticket(4) pad total(8) err(8) total_bytes(8) counters...

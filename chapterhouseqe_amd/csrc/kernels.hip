@@ -17,6 +17,7 @@
 // workgroup that has not started (no co-residency assumption).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "device_program.h"
 
 namespace chq {
@@ -40,6 +41,12 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// tell the compiler a wave-uniform value is uniform (moves it to SGPRs: scalar address math, saddr loads)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ unsigned lane_rank(u64 m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
@@ -165,6 +172,36 @@ struct Interp {
   }
 
   // ---- operand fetch ---------------------------------------------------------------------------
+  template <bool FULL>
+  __device__ __forceinline__ void fetch_values(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH]) {
+    // FULL: the wave's 64*R rows are all inside the batch -> element j*64+lane, no clamping (immediate offsets)
+#define IDX(j) (FULL ? (j) * 64 + lane : off(j))
+    switch (c.type) {
+      case T_I8: { const int8_t* p = (const int8_t*)c.values + w0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[IDX(j)]; } break;
+      case T_U8: { const uint8_t* p = (const uint8_t*)c.values + w0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = p[IDX(j)]; } break;
+      case T_I16: { const int16_t* p = (const int16_t*)c.values + w0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[IDX(j)]; } break;
+      case T_U16: { const uint16_t* p = (const uint16_t*)c.values + w0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = p[IDX(j)]; } break;
+      case T_I32: case T_U32: case T_F32: { const uint32_t* p = (const uint32_t*)c.values + w0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = p[IDX(j)]; } break;
+      case T_I64: case T_U64: case T_F64:
+        if constexpr (WIDE) { const uint2* p = (const uint2*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) { uint2 x = p[IDX(j)]; l[j] = x.x; h[j] = x.y; } }
+        break;
+      default: break;
+    }
+#undef IDX
+  }
+
   __device__ __forceinline__ void fetch_col(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
 #pragma unroll
     for (int j = 0; j < R; ++j) l[j] = 0;
@@ -172,30 +209,9 @@ struct Interp {
     for (int j = 0; j < RH; ++j) h[j] = 0;
     b = 0;
     if (nact > 0) {
-      switch (c.type) {
-        case T_I8: { const int8_t* p = (const int8_t*)c.values + w0;
-#pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[off(j)]; } break;
-        case T_U8: { const uint8_t* p = (const uint8_t*)c.values + w0;
-#pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = p[off(j)]; } break;
-        case T_I16: { const int16_t* p = (const int16_t*)c.values + w0;
-#pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[off(j)]; } break;
-        case T_U16: { const uint16_t* p = (const uint16_t*)c.values + w0;
-#pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = p[off(j)]; } break;
-        case T_I32: case T_U32: case T_F32: { const uint32_t* p = (const uint32_t*)c.values + w0;
-#pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = p[off(j)]; } break;
-        case T_I64: case T_U64: case T_F64:
-          if constexpr (WIDE) { const uint2* p = (const uint2*)c.values + w0;
-#pragma unroll
-            for (int j = 0; j < R; ++j) { uint2 x = p[off(j)]; l[j] = x.x; h[j] = x.y; } }
-          break;
-        case T_BOOL: b = fetch_flags(c.values, c.bool_bit_offset); break;
-        default: break;
-      }
+      if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
+      else if (nact == 64 * R) fetch_values<true>(c, l, h);
+      else fetch_values<false>(c, l, h);
     }
     v = c.validity ? (fetch_flags(c.validity, c.validity_bit_offset) & actv) : actv;
   }
@@ -527,15 +543,18 @@ struct TempLds {
 
 // ------------------------------------------------------------------------------------------------
 // filter_fused_kernel: predicate + order-preserving compaction of every fixed-width column, one pass.
-//   P(i): ticket -> interpret predicate -> ballots to LDS -> tile count -> publish AGGREGATE
-//   C(i): look-back -> tile base -> per column: load 64R rows per wave, store the selected ones
-// The loop runs P(i+1) before C(i).
+//   P(i): ticket -> interpret predicate -> per-lane selection flags to LDS, wave counts -> barrier -> tile
+//         count -> publish AGGREGATE
+//   C(i): look-back -> tile base -> barrier -> per column: load the wave's 64 R rows, store the selected ones
+// The loop runs P(i+1) before C(i): an aggregate is published a whole tile ahead of the point where the
+// successors' look-backs need it.  Everything a wave derives from the tile index / tile base goes through
+// readfirstlane so that global accesses are SGPR-base + 32-bit lane offset.
 // ------------------------------------------------------------------------------------------------
 template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
 __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams p) {
   constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
-  __shared__ u64 s_mask[2][R][NW];
+  __shared__ uint32_t s_sel[2][BLOCK];       // bit j of word t: row (wave, slot j, lane) of thread t is selected
   __shared__ unsigned s_wave_cnt[2][NW];
   __shared__ unsigned s_tot[2];
   __shared__ int64_t s_tile[2];
@@ -549,20 +568,18 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
   auto P = [&](int buf) {
     if (tid == 0) s_tile[buf] = (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
-    const int64_t tile = s_tile[buf];
+    const int64_t tile = uniform64(s_tile[buf]);
     if (tile >= ntiles) return;
     Interp<BLOCK, R, WIDE> it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
     it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE>&) {});
     const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
+    s_sel[buf][tid] = selv;
     unsigned cnt = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const u64 m = __ballot((selv >> j) & 1);
-      if (lane == 0) {
-        s_mask[buf][j][wv] = m;
-        if (p.sel_mask && it.w0 + 64 * j < p.nrows) p.sel_mask[(it.w0 >> 6) + j] = m;
-      }
+      if (p.sel_mask && lane == 0 && it.w0 + 64 * j < p.nrows) p.sel_mask[(it.w0 >> 6) + j] = m;
       cnt += __popcll(m);
     }
     if (lane == 0) s_wave_cnt[buf][wv] = cnt;
@@ -578,63 +595,77 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
   };
 
   auto C = [&](int buf) {
-    const int64_t tile = s_tile[buf];
+    const int64_t tile = uniform64(s_tile[buf]);
     if (wv == 0) {
       u64 excl = 0;
-      if (tile > 0) {
+      if (p.debug & 1) excl = (u64)(tile * TILE);
+      else if (tile > 0) {
         excl = lookback_exclusive(p.status, tile, 0, lane);
         if (lane == 0) st_store(&p.status[tile], ST_INC | (excl + s_tot[buf]));
       }
-      if (lane == 0) { s_base = excl; if (tile == ntiles - 1) *p.total = excl + s_tot[buf]; }
+      if (lane == 0) { s_base = excl; if (tile == ntiles - 1) *p.total = (p.debug & 1) ? (u64)p.nrows : excl + s_tot[buf]; }
     }
     __syncthreads();
     u64 off0 = s_base;
     for (int w = 0; w < wv; ++w) off0 += s_wave_cnt[buf][w];
+    off0 = (u64)uniform64((int64_t)off0);
     const int64_t w0 = tile * TILE + (int64_t)wv * 64 * R;
-    int64_t rem = p.nrows - w0;
+    const int64_t rem = p.nrows - w0;
     const int nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
-    if (p.grp_base && lane == 0 && nact > 0) {
+    if (nact <= 0) return;
+    const uint32_t selv = s_sel[buf][tid];
+    if (p.grp_base) {
       u64 run = off0;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        if (w0 + 64 * j < p.nrows) p.grp_base[(w0 >> 6) + j] = run;
-        run += __popcll(s_mask[buf][j][wv]);
+        const u64 m = __ballot((selv >> j) & 1);
+        if (lane == 0 && w0 + 64 * j < p.nrows) p.grp_base[(w0 >> 6) + j] = run;
+        run += __popcll(m);
       }
     }
-    if (nact > 0) {
-      for (int c = 0; c < p.n_out; ++c) {
+    const int ncopy = (p.debug & 2) ? p.n_out - 1 : p.n_out;
+    auto copy_columns = [&](auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      for (int c = 0; c < ncopy; ++c) {
         const OutCol oc = p.outs[c];
-        switch (oc.width) {
+        // CH values per lane are loaded (one contiguous 64-element run per instruction), then the selected ones are
+        // stored at off0 + (selected rows in earlier slots) + rank of the lane among the selected lanes of its slot
+#define LOAD_IDX(j) (FULL ? (j) * 64 + lane : (((j) * 64 + lane) < nact ? ((j) * 64 + lane) : nact - 1))
 #define COPY_COL(TY, CH)                                                                              \
   { const TY* src = (const TY*)oc.in + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;            \
     _Pragma("unroll") for (int j0 = 0; j0 < R; j0 += CH) {                                             \
       TY v[CH];                                                                                        \
-      _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) { int o = (j0 + jj) * 64 + lane; v[jj] = src[o < nact ? o : nact - 1]; } \
+      _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) v[jj] = src[LOAD_IDX(j0 + jj)];                \
       _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) {                                              \
-        const u64 m = s_mask[buf][j0 + jj][wv];                                                        \
-        if ((m >> lane) & 1) dst[run + lane_rank(m)] = v[jj];                                          \
+        const bool sel = (selv >> (j0 + jj)) & 1;                                                      \
+        const u64 m = __ballot(sel);                                                                   \
+        if (sel) dst[run + lane_rank(m)] = v[jj];                                                      \
         run += __popcll(m); } } }
+        switch (oc.width) {
           case 1: COPY_COL(uint8_t, R) break;
           case 2: COPY_COL(uint16_t, R) break;
           case 4: COPY_COL(uint32_t, R) break;
           case 8: COPY_COL(uint2, (R >= 8 ? 8 : R)) break;
-          default: {   // 16-byte values (decimal128 ...): no private array (it would be promoted to LDS)
+          default: {   // 16-byte values (decimal128 ...): named registers, a private array would be promoted to LDS
             const uint4* src = (const uint4*)oc.in + w0; uint4* dst = (uint4*)oc.out + off0; unsigned run = 0;
 #pragma unroll
             for (int j0 = 0; j0 < R; j0 += 2) {
-              const int o0 = j0 * 64 + lane, o1 = o0 + 64;
-              const uint4 v0 = src[o0 < nact ? o0 : nact - 1], v1 = src[o1 < nact ? o1 : nact - 1];
-              const u64 m0 = s_mask[buf][j0][wv], m1 = s_mask[buf][j0 + 1][wv];
-              if ((m0 >> lane) & 1) dst[run + lane_rank(m0)] = v0;
-              run += __popcll(m0);
-              if ((m1 >> lane) & 1) dst[run + lane_rank(m1)] = v1;
-              run += __popcll(m1);
+              const uint4 va = src[LOAD_IDX(j0)], vb = src[LOAD_IDX(j0 + 1)];
+              const bool sa = (selv >> j0) & 1, sb = (selv >> (j0 + 1)) & 1;
+              const u64 ma = __ballot(sa);
+              if (sa) dst[run + lane_rank(ma)] = va;
+              run += __popcll(ma);
+              const u64 mb = __ballot(sb);
+              if (sb) dst[run + lane_rank(mb)] = vb;
+              run += __popcll(mb);
             }
           } break;
-#undef COPY_COL
         }
+#undef COPY_COL
+#undef LOAD_IDX
       }
-    }
+    };
+    if (nact == 64 * R) copy_columns(std::true_type{}); else copy_columns(std::false_type{});
   };
 
   P(0);
@@ -872,6 +903,8 @@ hipError_t launch_filter(const FilterParams& p, int tile_kind, int grid, hipStre
   switch (tile_kind) {
     case 0: hipLaunchKernelGGL((filter_fused_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
     case 1: hipLaunchKernelGGL((filter_fused_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL((filter_fused_kernel<512, 16, false, 0>), dim3(grid), dim3(512), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((filter_fused_kernel<256, 16, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
     default: hipLaunchKernelGGL((filter_fused_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
   }
   return hipGetLastError();
