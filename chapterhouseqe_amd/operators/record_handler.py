@@ -1,0 +1,74 @@
+"""RecordHandler: the exchange-side API the operator tasks call.
+
+Reference: src/handlers/exchange_handlers/record_handler/record_handler.rs
+  ExchangeRecord :48-52, initiate :79-125, next_record :127-214, complete_record :216-251,
+  send_record_to_outbound_exchange :253-278, close.
+"""
+from __future__ import annotations
+
+import dataclasses
+import time
+from typing import Any, List, Optional
+
+from .exchange_operator import NONE_AVAILABLE, NONE_LEFT, ExchangeOperator
+
+
+class RecordHandlerError(Exception):
+    pass
+
+
+@dataclasses.dataclass
+class ExchangeRecord:
+    record_id: int
+    record: Any
+    table_aliases: List[List[str]]
+
+
+class RecordHandler:
+    def __init__(self, operator_id: str, operator_instance_id: int, inbound_exchanges: List[ExchangeOperator],
+                 outbound_exchange: Optional[ExchangeOperator], none_available_wait_time_s: float = 0.05):
+        self.operator_id = operator_id
+        self.operator_instance_id = operator_instance_id
+        self.inbound_exchanges = inbound_exchanges
+        self.outbound_exchange = outbound_exchange
+        self.none_available_wait_time_s = none_available_wait_time_s      # 50 ms in the reference (:104)
+        self.tracked_records = {}
+
+    @staticmethod
+    def initiate(op_in_config, inbound_exchanges: List[ExchangeOperator], outbound_exchange: Optional[ExchangeOperator]) -> "RecordHandler":
+        return RecordHandler(op_in_config.operator_id, op_in_config.instance_id, inbound_exchanges, outbound_exchange)
+
+    def next_record(self, max_wait_s: Optional[float] = None) -> Optional[ExchangeRecord]:
+        """Pull the next record from the FIRST inbound exchange (a producer reads only its first inbound
+        exchange, record_handler.rs:133-138). Returns None when the exchange has nothing left."""
+        if not self.inbound_exchanges:
+            raise RecordHandlerError("inbound exchanges is empty")
+        ex = self.inbound_exchanges[0]
+        deadline = None if max_wait_s is None else time.monotonic() + max_wait_s
+        while True:
+            got = ex.get_next_record(self.operator_id, self.operator_instance_id)
+            if got == NONE_LEFT:
+                return None
+            if got == NONE_AVAILABLE:
+                if deadline is not None and time.monotonic() > deadline:
+                    return None
+                time.sleep(self.none_available_wait_time_s)
+                continue
+            record_id, record, aliases = got
+            self.tracked_records[record_id] = 0
+            ex.heartbeat(self.operator_id, record_id)
+            return ExchangeRecord(record_id, record, aliases)
+
+    def send_record_to_outbound_exchange(self, record_id: int, record: Any, table_aliases: List[List[str]]) -> None:
+        if self.outbound_exchange is None:
+            raise RecordHandlerError("outbound exchange is none")
+        self.outbound_exchange.send_record(record_id, record, table_aliases)
+
+    def complete_record(self, rec: ExchangeRecord) -> None:
+        if rec.record_id not in self.tracked_records:
+            raise RecordHandlerError(f"unable to find tracked record: {rec.record_id}")
+        idx = self.tracked_records.pop(rec.record_id)
+        self.inbound_exchanges[idx].operator_completed_record_processing(self.operator_id, rec.record_id)
+
+    def close(self) -> None:
+        self.tracked_records.clear()

@@ -1,0 +1,250 @@
+"""Operator tasks and the plugin API they register through.
+
+Reference (OPS = src/handlers/operator_handler/operators):
+  TaskBuilder trait                         OPS/traits.rs:22-36
+  OperatorTaskRegistry                      OPS/operator_task_registry.rs:40-162
+  FilterConfig / FilterTask / FilterTaskBuilder        OPS/filter_tasks/{config.rs, filter_task.rs:30-199}
+  MaterializeFilesConfig / MaterializeFilesTask / ...  OPS/materialize_tasks/{config.rs, materialize_files_task.rs:30-230}
+  OperatorTask::{Filter{expr}, MaterializeFiles{data_format, fields}}  src/planner/physical_planner.rs:58-65
+
+The hot loops call `record_utils.filter_record` / `project_record` exactly where the reference does
+(filter_task.rs:99, materialize_files_task.rs:110); here those are the HIP kernels.  The control plane around
+them (message router, pipes, TCP) is out of scope: `build` receives the exchanges directly.
+"""
+from __future__ import annotations
+
+import abc
+import dataclasses
+import os
+import uuid
+from typing import Any, Callable, List, Optional, Sequence
+
+from .. import record_utils
+from .. import sqlast as A
+from .exchange_operator import ExchangeOperator
+from .record_handler import RecordHandler
+
+
+# ---- planner types the tasks consume ------------------------------------------------------------------
+@dataclasses.dataclass(frozen=True)
+class FilterOperatorTask:
+    """planner::OperatorTask::Filter { expr }"""
+    expr: A.Expr
+
+    def task_name(self) -> str:
+        return "filter"
+
+
+@dataclasses.dataclass(frozen=True)
+class MaterializeFilesOperatorTask:
+    """planner::OperatorTask::MaterializeFiles { data_format, fields }"""
+    data_format: str
+    fields: Sequence[A.SelectItem]
+
+    def task_name(self) -> str:
+        return "materialize_files"
+
+
+@dataclasses.dataclass
+class OperatorInstanceConfig:
+    """operator_handler_state.rs:28-35 (fields the tasks use)"""
+    instance_id: int
+    operator_id: str
+    query_id: int
+    task: Any
+    device_id: int = 0
+
+
+# ---- plugin API ------------------------------------------------------------------------------------------
+class TaskBuilder(abc.ABC):
+    """OPS/traits.rs:22-36.  `build` returns a callable that runs the task to completion and returns None on
+    success or the error (the reference sends that through a oneshot channel)."""
+
+    @abc.abstractmethod
+    def build(self, op_in_config: OperatorInstanceConfig, inbound_exchanges: List[ExchangeOperator],
+              outbound_exchange: Optional[ExchangeOperator]) -> Callable[[], Optional[Exception]]:
+        ...
+
+
+class OperatorTaskRegistryError(Exception):
+    pass
+
+
+class OperatorTaskRegistry:
+    def __init__(self):
+        self.filter_task: Optional[TaskBuilder] = None
+        self.materialize_files_task: Optional[TaskBuilder] = None
+        self.materialize_data_formats: List[str] = []
+
+    def add_filter_task_builder(self, builder: TaskBuilder) -> "OperatorTaskRegistry":
+        if self.filter_task is not None:
+            raise OperatorTaskRegistryError("filter task builder already set")
+        self.filter_task = builder
+        return self
+
+    def add_materialize_files_builder(self, builder: TaskBuilder, data_formats: List[str]) -> "OperatorTaskRegistry":
+        if self.materialize_files_task is not None:
+            raise OperatorTaskRegistryError("materialize file task builder already set")
+        self.materialize_files_task = builder
+        self.materialize_data_formats = list(data_formats)
+        return self
+
+    def find_task_builder(self, task) -> Optional[TaskBuilder]:
+        if isinstance(task, FilterOperatorTask):
+            return self.filter_task
+        if isinstance(task, MaterializeFilesOperatorTask):
+            if task.data_format in self.materialize_data_formats:
+                return self.materialize_files_task
+        return None
+
+
+# ---- filter --------------------------------------------------------------------------------------------------
+@dataclasses.dataclass(frozen=True)
+class FilterConfig:
+    expr: A.Expr
+
+    @staticmethod
+    def try_from(op_in_config: OperatorInstanceConfig) -> "FilterConfig":
+        if not isinstance(op_in_config.task, FilterOperatorTask):
+            raise ValueError("operator instance config is not a filter task")
+        return FilterConfig(op_in_config.task.expr)
+
+
+class FilterTask:
+    def __init__(self, op_in_config: OperatorInstanceConfig, filter_config: FilterConfig,
+                 inbound_exchanges, outbound_exchange, filter_fn=None, ctx=None):
+        self.operator_instance_config = op_in_config
+        self.filter_config = filter_config
+        self.inbound_exchanges = inbound_exchanges
+        self.outbound_exchange = outbound_exchange
+        self._filter = filter_fn
+        self._ctx = ctx
+        self.records_processed = 0
+        self.rows_in = 0
+        self.rows_out = 0
+
+    def _filter_record(self, rec, aliases):
+        if self._filter is not None:
+            return self._filter(rec, aliases, self.filter_config.expr)
+        if self._ctx is None:
+            self._ctx = record_utils.Context(self.operator_instance_config.device_id)
+        return record_utils.filter_record(rec, aliases, self.filter_config.expr, ctx=self._ctx)
+
+    def async_main(self) -> None:
+        """filter_task.rs:65-142: pull -> filter -> push (same record id) -> ack"""
+        rec_handler = RecordHandler.initiate(self.operator_instance_config, self.inbound_exchanges, self.outbound_exchange)
+        while True:
+            exchange_rec = rec_handler.next_record()
+            if exchange_rec is None:
+                break
+            filtered_rec = self._filter_record(exchange_rec.record, exchange_rec.table_aliases)
+            rec_handler.send_record_to_outbound_exchange(exchange_rec.record_id, filtered_rec, exchange_rec.table_aliases)
+            rec_handler.complete_record(exchange_rec)
+            self.records_processed += 1
+            self.rows_in += exchange_rec.record.num_rows
+            self.rows_out += filtered_rec.num_rows
+        rec_handler.close()
+
+
+class FilterTaskBuilder(TaskBuilder):
+    """The GPU filter operator. Swap it in with `OperatorTaskRegistry.add_filter_task_builder` -- the planner's
+    DAG and the exchanges are untouched (operator_task_registry.rs:51-57)."""
+
+    def __init__(self, filter_fn=None):
+        self._filter_fn = filter_fn
+
+    def build(self, op_in_config, inbound_exchanges, outbound_exchange):
+        task = FilterTask(op_in_config, FilterConfig.try_from(op_in_config), inbound_exchanges, outbound_exchange,
+                          filter_fn=self._filter_fn)
+
+        def run():
+            try:
+                task.async_main()
+                return None
+            except Exception as err:   # noqa: BLE001 -- any error ends the instance (producer_operator.rs:179-183)
+                return err
+
+        run.task = task
+        return run
+
+
+# ---- materialize ----------------------------------------------------------------------------------------------
+@dataclasses.dataclass(frozen=True)
+class MaterializeFilesConfig:
+    data_format: str
+    fields: Sequence[A.SelectItem]
+
+    @staticmethod
+    def try_from(op_in_config: OperatorInstanceConfig) -> "MaterializeFilesConfig":
+        if not isinstance(op_in_config.task, MaterializeFilesOperatorTask):
+            raise ValueError("operator instance config is not a materialize files task")
+        return MaterializeFilesConfig(op_in_config.task.data_format, op_in_config.task.fields)
+
+
+class MaterializeFilesTask:
+    def __init__(self, op_in_config, config: MaterializeFilesConfig, inbound_exchanges, outbound_exchange,
+                 storage_root: str, project_fn=None, ctx=None):
+        self.operator_instance_config = op_in_config
+        self.materialize_file_config = config
+        self.inbound_exchanges = inbound_exchanges
+        self.outbound_exchange = outbound_exchange
+        self.storage_root = storage_root
+        self._project = project_fn
+        self._ctx = ctx
+        self.files_written: List[str] = []
+
+    def _project_record(self, rec, aliases):
+        if self._project is not None:
+            return self._project(self.materialize_file_config.fields, rec, aliases)
+        if self._ctx is None:
+            self._ctx = record_utils.Context(self.operator_instance_config.device_id)
+        return record_utils.project_record(self.materialize_file_config.fields, rec, aliases, ctx=self._ctx, device_result=False)
+
+    def async_main(self) -> None:
+        """materialize_files_task.rs:68-170: pull -> project -> write /query_results/<uuid>/rec_<id>.parquet -> ack.
+        (The parquet encode itself is outside the hot path; pyarrow writes it.)"""
+        import pyarrow.parquet as pq
+        rec_handler = RecordHandler.initiate(self.operator_instance_config, self.inbound_exchanges, self.outbound_exchange)
+        query_uuid = uuid.UUID(int=self.operator_instance_config.query_id)
+        out_dir = os.path.join(self.storage_root, "query_results", str(query_uuid))
+        os.makedirs(out_dir, exist_ok=True)
+        while True:
+            exchange_rec = rec_handler.next_record()
+            if exchange_rec is None:
+                break
+            proj_rec = self._project_record(exchange_rec.record, exchange_rec.table_aliases)
+            if hasattr(proj_rec, "to_host"):
+                proj_rec = proj_rec.to_host()
+            path = os.path.join(out_dir, f"rec_{exchange_rec.record_id}.parquet")
+            import pyarrow as pa
+            pq.write_table(pa.Table.from_batches([proj_rec]), path)
+            self.files_written.append(path)
+            rec_handler.complete_record(exchange_rec)
+        rec_handler.close()
+
+
+class MaterializeFilesTaskBuilder(TaskBuilder):
+    def __init__(self, storage_root: str, project_fn=None):
+        self.storage_root = storage_root
+        self._project_fn = project_fn
+
+    def build(self, op_in_config, inbound_exchanges, outbound_exchange):
+        task = MaterializeFilesTask(op_in_config, MaterializeFilesConfig.try_from(op_in_config), inbound_exchanges,
+                                    outbound_exchange, self.storage_root, project_fn=self._project_fn)
+
+        def run():
+            try:
+                task.async_main()
+                return None
+            except Exception as err:   # noqa: BLE001
+                return err
+
+        run.task = task
+        return run
+
+
+def build_default_operator_task_registry(storage_root: str) -> OperatorTaskRegistry:
+    """operator_task_registry.rs:150-162 with the GPU builders swapped in."""
+    return (OperatorTaskRegistry()
+            .add_filter_task_builder(FilterTaskBuilder())
+            .add_materialize_files_builder(MaterializeFilesTaskBuilder(storage_root), ["parquet"]))

