@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the other BASELINE.json configs (SURVEY.md section 8 d) on ONE GPU.  bench.py stays the
+headline (config 2); this script reports kernel-level numbers for configs 2b/3/4/5-shape so DESIGN.md can quote
+them.  Every case is checked against the CPU oracle on a prefix before it is timed.
+
+    python bench_configs.py [--scale 1.0] [--out profiles/r1/configs.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0, help="scale every row count (1.0 = BASELINE sizes)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import pyarrow as pa
+    import torch
+
+    import chapterhouseqe_amd as chq
+    from chapterhouseqe_amd.sqlparse import parse_expr, parse_select
+    from oracle import oracle as O
+    from tests.helpers import batches_identical, explain_diff
+
+    dev = torch.device("cuda", 0)
+    ctx = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.set_option("time_kernels", 1)
+    results = []
+
+    def gen(n, spec, seed):
+        """spec: list of (name, kind, *params); returns (tensors keepalive, column tuples, host builder)"""
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        keep, cols = [], []
+        for item in spec:
+            name, kind = item[0], item[1]
+            if kind == "f32":
+                t = torch.empty(n, dtype=torch.float32, device=dev).uniform_(item[2], item[3], generator=g)
+                keep.append(t); cols.append((name, "f", t.data_ptr()))
+            elif kind == "i32":
+                t = torch.randint(item[2], item[3], (n,), dtype=torch.int32, device=dev, generator=g)
+                keep.append(t); cols.append((name, "i", t.data_ptr()))
+            elif kind == "id":
+                t = torch.arange(n, dtype=torch.int32, device=dev)
+                keep.append(t); cols.append((name, "i", t.data_ptr()))
+            elif kind == "utf8":
+                L = item[2]
+                assert n * L < 2**31, "Utf8 (int32 offsets) holds < 2 GiB of bytes per array: lower the row count"
+                chars = torch.randint(ord("a"), ord("z") + 1, (n * L,), dtype=torch.uint8, device=dev, generator=g)
+                offs = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L).to(torch.int32)
+                keep += [chars, offs]; cols.append((name, "u", offs.data_ptr(), chars.data_ptr()))
+        torch.cuda.synchronize()
+        return keep, cols
+
+    def host_prefix(keep, spec, m):
+        arrays, fields = [], []
+        k = 0
+        for item in spec:
+            name, kind = item[0], item[1]
+            if kind == "utf8":
+                L = item[2]
+                chars, offs = keep[k], keep[k + 1]; k += 2
+                arr = pa.Array.from_buffers(pa.utf8(), m, [None, pa.py_buffer(offs[: m + 1].cpu().numpy().tobytes()),
+                                                          pa.py_buffer(chars[: m * L].cpu().numpy().tobytes())])
+                arrays.append(arr); fields.append(pa.field(name, pa.utf8(), False))
+            else:
+                t = keep[k]; k += 1
+                arrays.append(pa.array(t[:m].cpu().numpy())); fields.append(pa.field(name, arrays[-1].type, False))
+        return pa.RecordBatch.from_arrays(arrays, schema=pa.schema(fields))
+
+    def run_case(name, n, spec, where, select=None, seed=1, note=""):
+        if args.only and args.only not in name:
+            return
+        n = max(1024, int(n * args.scale))
+        keep, cols = gen(n, spec, seed)
+        rec = chq.DeviceRecordBatch.from_device_pointers(cols, n, ctx=ctx, keepalive=keep)
+        al = [[] for _ in cols]
+        pred = parse_expr(where)
+        fields = parse_select(f"select {select} from t").projection if select else None
+        # parity on a prefix
+        m = min(n, 2_000_000)
+        host = host_prefix(keep, spec, m)
+        sub = chq.DeviceRecordBatch.from_device_pointers(cols, m, ctx=ctx)
+        got = chq.filter_record(sub, al, pred, ctx=ctx)
+        exp = O.filter_record(host, al, pred)
+        ok = batches_identical(got.to_host(), exp)
+        if fields:
+            gp = chq.project_record(fields, got, al, ctx=ctx).to_host()
+            ok = ok and batches_identical(gp, O.project_record(fields, exp, al), nan_payload=False)
+        got.release()
+        if not ok:
+            raise SystemExit(f"{name}: GPU result differs from the oracle")
+        # timing
+        fk, pk, wall = [], [], []
+        for it in range(args.steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = chq.filter_record(rec, al, pred, ctx=ctx)
+            st = ctx.last_stats()
+            t1 = time.perf_counter()
+            pw = None
+            if fields:
+                p_out = chq.project_record(fields, out, al, ctx=ctx)
+                torch.cuda.synchronize()
+                pw = time.perf_counter() - t1
+                p_out.release()
+            rows_out = out.num_rows
+            out.release()
+            if it:
+                fk.append(st["kernel_ns"] / 1e6); wall.append((t1 - t0) * 1e3)
+                if pw is not None:
+                    pk.append(pw * 1e3)
+        fk.sort(); wall.sort(); pk.sort()
+        alg = st["bytes_read_alg"] + st["bytes_written_alg"]
+        # Utf8 / Boolean columns are compacted by follow-up kernels whose bytes the library does not count: add them
+        str_bytes = 0
+        for item in spec:
+            if item[1] == "utf8":
+                str_bytes += n * (4 + item[2]) + rows_out * (4 + item[2])
+        r = {"case": name, "rows": n, "rows_out": rows_out, "selectivity": rows_out / n, "where": where, "select": select,
+             "filter_kernel_ms": fk[len(fk) // 2], "filter_wall_ms": wall[len(wall) // 2], "launches": st["launches"],
+             "alg_bytes_fixed_width": alg, "alg_bytes_strings": str_bytes,
+             "fused_kernel_GBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9,
+             "whole_filter_GBps": (alg + str_bytes) / (wall[len(wall) // 2] * 1e-3) / 1e9,
+             "rows_per_s_wall": n / (wall[len(wall) // 2] * 1e-3), "validated_rows": m, "note": note}
+        r["fused_kernel_frac_of_8TBps"] = r["fused_kernel_GBps"] / HBM_PEAK
+        r["whole_filter_frac_of_8TBps"] = r["whole_filter_GBps"] / HBM_PEAK
+        if pk:
+            r["project_wall_ms"] = pk[len(pk) // 2]
+        results.append(r)
+        print(json.dumps(r), flush=True)
+        del rec, keep
+        ctx.set_option("trim_pool", 1)
+        torch.cuda.empty_cache()
+
+    f3 = [("value0", "f32", 0, 100), ("value1", "f32", 0, 100), ("value2", "f32", 0, 100)]
+    run_case("config2 value2>10 (s~0.9)", 1_000_000_000, f3, "value2 > 10.0", seed=0xC0FFEE)
+    run_case("config2b value2>90 (s~0.1)", 1_000_000_000, f3, "value2 > 90.0", seed=0xC0FFEE)
+    run_case("config2c value2>50 (s~0.5)", 1_000_000_000, f3, "value2 > 50.0", seed=0xC0FFEE)
+    c3 = [("a", "i32", 0, 1000), ("b", "f32", 0, 100), ("c", "f32", 0, 1100), ("d", "i32", 0, 10), ("e", "f32", 0, 2)]
+    run_case("config3 compound + projection", 1_000_000_000, c3, "a + b > c and d < 5.0 or e > 1.0",
+             select="a, a + b as ab, d * 2 as d2, e / 3.0 as e3", seed=3)
+    c4 = [("id", "id"), ("value1", "utf8", 100), ("value2", "f32", 0, 100)]
+    run_case("config4 wide strings id>25 (s~1)", 20_000_000, c4, "id > 25", seed=4)
+    n4 = max(1024, int(20_000_000 * args.scale))
+    run_case("config4b wide strings id>n/2 (s~0.5)", 20_000_000, c4, f"id > {n4 // 2}", seed=4)
+    run_case("config4c wide strings value2<10 (s~0.1)", 20_000_000, c4, "value2 < 10.0", seed=4)
+    c5 = [("id", "id"), ("value1", "utf8", 8), ("value2", "f32", 0, 100)]
+    run_case("config5-shape id%2=0, one record batch", 250_000_000, c5, "id % 2 = 0", seed=5,
+             note="huge_simple.sql shape; one Utf8 array holds < 2 GiB of bytes (int32 offsets), so a 1.25 B-row GPU shard is "
+                  "five such batches")
+    if args.out:
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump(results, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

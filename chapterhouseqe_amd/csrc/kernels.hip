@@ -151,9 +151,12 @@ struct Interp {
     w0 = tile_start + (int64_t)wv * 64 * R;
     int64_t rem = nrows - w0;
     nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
-    actv = 0;
+    if (nact == 64 * R) actv = R == 32 ? 0xffffffffu : ((1u << R) - 1u);
+    else {
+      actv = 0;
 #pragma unroll
-    for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
+      for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
+    }
   }
   __device__ __forceinline__ int off(int j) const {  // clamped element offset of (j, lane) inside the wave's rows
     int o = j * 64 + lane;
@@ -203,15 +206,17 @@ struct Interp {
   }
 
   __device__ __forceinline__ void fetch_col(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
-#pragma unroll
-    for (int j = 0; j < R; ++j) l[j] = 0;
-#pragma unroll
-    for (int j = 0; j < RH; ++j) h[j] = 0;
     b = 0;
-    if (nact > 0) {
-      if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
-      else if (nact == 64 * R) fetch_values<true>(c, l, h);
-      else fetch_values<false>(c, l, h);
+    if (nact == 64 * R && c.type != T_BOOL) fetch_values<true>(c, l, h);
+    else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) l[j] = 0;
+#pragma unroll
+      for (int j = 0; j < RH; ++j) h[j] = 0;
+      if (nact > 0) {
+        if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
+        else fetch_values<false>(c, l, h);
+      }
     }
     v = c.validity ? (fetch_flags(c.validity, c.validity_bit_offset) & actv) : actv;
   }
@@ -263,7 +268,9 @@ struct Interp {
   }
 
   // ---- arithmetic: arrow-arith numeric::{add,sub,mul,div,rem}; checked for integers ----------------
-  __device__ __forceinline__ void arith(int op, int t, bool rev, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], u64* err, uint32_t ref_order) {
+  __device__ __forceinline__ void arith(int op, int t, bool rev, const uint32_t (&bl_)[R], const uint32_t (&bh_)[RH], u64* err, uint32_t ref_order) {
+#define bl(j) bl_[j]
+#define bh(j) bh_[j]
     const int cls = vclass(t);
     int errj = -1; uint32_t errc = 0;   // first offending slot of this lane (= its smallest row)
 #define BAD(code) do { if (live && errj < 0) { errj = j; errc = (code); } } while (0)
@@ -271,7 +278,7 @@ struct Interp {
       int64_t tlo, thi; int_range(t, tlo, thi);
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const int32_t x = (int32_t)lo[j], y = (int32_t)bl[j];
+        const int32_t x = (int32_t)lo[j], y = (int32_t)bl(j);
         const int32_t a = rev ? y : x, b = rev ? x : y;
         const bool live = (validv >> j) & 1;
         int64_t w;
@@ -289,7 +296,7 @@ struct Interp {
       int64_t tlo, thi; int_range(t, tlo, thi);
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const uint32_t x = lo[j], y = bl[j];
+        const uint32_t x = lo[j], y = bl(j);
         const uint32_t a = rev ? y : x, b = rev ? x : y;
         const bool live = (validv >> j) & 1;
         int64_t w;
@@ -306,7 +313,7 @@ struct Interp {
     } else if (cls == C_F32) {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const float x = __uint_as_float(lo[j]), y = __uint_as_float(bl[j]);
+        const float x = __uint_as_float(lo[j]), y = __uint_as_float(bl(j));
         const float a = rev ? y : x, b = rev ? x : y;
         float w;
         switch (op) {
@@ -319,7 +326,7 @@ struct Interp {
       if (cls == C_I64) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const long long x = (long long)PACK64(lo[j], hi[j]), y = (long long)PACK64(bl[j], bh[j]);
+          const long long x = (long long)PACK64(lo[j], hi[j]), y = (long long)PACK64(bl(j), bh(j));
           const long long a = rev ? y : x, b = rev ? x : y;
           long long w = 0;
           const bool live = (validv >> j) & 1;
@@ -337,7 +344,7 @@ struct Interp {
       } else if (cls == C_U64) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const u64 x = PACK64(lo[j], hi[j]), y = PACK64(bl[j], bh[j]);
+          const u64 x = PACK64(lo[j], hi[j]), y = PACK64(bl(j), bh(j));
           const u64 a = rev ? y : x, b = rev ? x : y;
           u64 w = 0;
           const bool live = (validv >> j) & 1;
@@ -355,7 +362,7 @@ struct Interp {
       } else if (cls == C_F64) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const double x = __longlong_as_double((long long)PACK64(lo[j], hi[j])), y = __longlong_as_double((long long)PACK64(bl[j], bh[j]));
+          const double x = __longlong_as_double((long long)PACK64(lo[j], hi[j])), y = __longlong_as_double((long long)PACK64(bl(j), bh(j)));
           const double a = rev ? y : x, b = rev ? x : y;
           double w;
           switch (op) {
@@ -370,36 +377,44 @@ struct Interp {
 #undef BAD
     // arrow's try_binary / try_unary stop at the first offending valid element: report (node, row, kind)
     if (__any(errj >= 0)) { if (errj >= 0) report_error(err, ref_order, w0 + 64 * errj + lane, errc); }
+#undef bl
+#undef bh
   }
 
   // ---- comparisons: arrow-ord cmp::*; floats by IEEE totalOrder ------------------------------------
   __device__ __forceinline__ void compare(int op, int t, bool rev, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], uint32_t bb) {
     const int cls = vclass(t);
-    uint32_t ltv = 0, eqv = 0;
     if (cls == C_BOOL) {
       const uint32_t a = rev ? bb : bitsv, b = rev ? bitsv : bb;
-      ltv = ~a & b; eqv = ~(a ^ b);
-    } else {
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        bool l_ = false, e_ = false;
-        if (cls == C_I32) { const int32_t x = (int32_t)lo[j], y = (int32_t)bl[j]; const int32_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
-        else if (cls == C_U32) { const uint32_t x = lo[j], y = bl[j]; const uint32_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
-        else if (cls == C_F32) { const int32_t x = f32_key(lo[j]), y = f32_key(bl[j]); const int32_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
-        else if constexpr (WIDE) {
-          if (cls == C_I64) { const int64_t x = (int64_t)PACK64(lo[j], hi[j]), y = (int64_t)PACK64(bl[j], bh[j]); const int64_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
-          else if (cls == C_U64) { const uint64_t x = PACK64(lo[j], hi[j]), y = PACK64(bl[j], bh[j]); const uint64_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
-          else { const int64_t x = f64_key(PACK64(lo[j], hi[j])), y = f64_key(PACK64(bl[j], bh[j])); const int64_t a = rev ? y : x, b = rev ? x : y; l_ = a < b; e_ = a == b; }
-        }
-        ltv |= (uint32_t)l_ << j; eqv |= (uint32_t)e_ << j;
+      const uint32_t ltv = ~a & b, eqv = ~(a ^ b);
+      uint32_t r;
+      switch (op) {
+        case OP_EQ: r = eqv; break; case OP_NE: r = ~eqv; break; case OP_LT: r = ltv; break;
+        case OP_LE: r = ltv | eqv; break; case OP_GT: r = ~(ltv | eqv); break; default: r = ~ltv; break;
       }
+      bitsv = r & actv;
+      return;
     }
-    uint32_t r;
-    switch (op) {
-      case OP_EQ: r = eqv; break; case OP_NE: r = ~eqv; break; case OP_LT: r = ltv; break;
-      case OP_LE: r = ltv | eqv; break; case OP_GT: r = ~(ltv | eqv); break; default: r = ~ltv; break;
+    // every operator is one primitive, possibly negated:  EQ: x==y  NE: !(x==y)  LT: a<b  GE: !(a<b)  GT: b<a  LE: !(b<a)
+    // with (a, b) = rev ? (y, x) : (x, y); x = accumulator, y = operand
+    const bool want_eq = op == OP_EQ || op == OP_NE;
+    const bool negate = op == OP_NE || op == OP_GE || op == OP_LE;
+    const bool swap = (op == OP_GT || op == OP_LE) != rev;      // compute y < x instead of x < y
+    uint32_t r = 0;
+#define CMP_LOOPS(TY, XJ, YJ)                                                                              \
+  { if (want_eq) { _Pragma("unroll") for (int j = 0; j < R; ++j) { const TY x = (XJ), y = (YJ); r |= (uint32_t)(x == y) << j; } } \
+    else if (swap) { _Pragma("unroll") for (int j = 0; j < R; ++j) { const TY x = (XJ), y = (YJ); r |= (uint32_t)(y < x) << j; } }  \
+    else { _Pragma("unroll") for (int j = 0; j < R; ++j) { const TY x = (XJ), y = (YJ); r |= (uint32_t)(x < y) << j; } } }
+    if (cls == C_I32) CMP_LOOPS(int32_t, (int32_t)lo[j], (int32_t)bl[j])
+    else if (cls == C_U32) CMP_LOOPS(uint32_t, lo[j], bl[j])
+    else if (cls == C_F32) CMP_LOOPS(int32_t, f32_key(lo[j]), f32_key(bl[j]))   // IEEE totalOrder through the integer key
+    else if constexpr (WIDE) {
+      if (cls == C_I64) CMP_LOOPS(int64_t, (int64_t)PACK64(lo[j], hi[j]), (int64_t)PACK64(bl[j], bh[j]))
+      else if (cls == C_U64) CMP_LOOPS(uint64_t, PACK64(lo[j], hi[j]), PACK64(bl[j], bh[j]))
+      else CMP_LOOPS(int64_t, f64_key(PACK64(lo[j], hi[j])), f64_key(PACK64(bl[j], bh[j])))
     }
-    bitsv = r & actv;
+#undef CMP_LOOPS
+    bitsv = (negate ? ~r : r) & actv;
   }
 
   // ---- Utf8 comparison of a column against a scalar string or another column ------------------------
@@ -437,10 +452,6 @@ struct Interp {
   // numeric temporaries live in LDS: tmp_flags [slot][BLOCK] validity flags, tmp_num [slot][2][R][BLOCK] values
   template <typename StoreFn>
   __device__ __forceinline__ void run(const ProgramBlock& pb, u64* err, uint32_t* tmp_flags, uint32_t* tmp_num, StoreFn&& store) {
-#pragma unroll
-    for (int j = 0; j < R; ++j) lo[j] = 0;
-#pragma unroll
-    for (int j = 0; j < RH; ++j) hi[j] = 0;
     bitsv = 0; validv = actv;
     int acc_type = T_BOOL;
     const int tix = wv * 64 + lane;
@@ -450,14 +461,22 @@ struct Interp {
     for (int pc = 0; pc < pb.n_instr; ++pc) {
       const Instr in = pb.prog[pc];
       const bool rev = in.flags & IF_REV;
+      const bool bconst = in.src_kind == SRC_CONST;
+      const uint32_t cl = (uint32_t)in.imm, ch = (uint32_t)(in.imm >> 32);
+      if (in.op == OP_LOAD && in.src_kind == SRC_COL) {   // straight into the accumulator
+        fetch_col(pb.refs[in.src_idx], lo, hi, bitsv, validv);
+        convert(in.src_type, in.type, lo, hi, bitsv);
+        acc_type = in.type;
+        continue;
+      }
       if (in.src_kind == SRC_COL) {
         fetch_col(pb.refs[in.src_idx], bl, bh, bb, bv);
         if (in.op != OP_STRCMP) convert(in.src_type, in.type, bl, bh, bb);
-      } else if (in.src_kind == SRC_CONST) {
+      } else if (bconst) {   // all slots hold the same value: after unrolling the compiler keeps one copy
 #pragma unroll
-        for (int j = 0; j < R; ++j) bl[j] = (uint32_t)in.imm;
+        for (int j = 0; j < R; ++j) bl[j] = cl;
 #pragma unroll
-        for (int j = 0; j < RH; ++j) bh[j] = (uint32_t)(in.imm >> 32);
+        for (int j = 0; j < RH; ++j) bh[j] = ch;
         bb = (in.imm & 1) ? actv : 0; bv = actv;
       } else if (in.src_kind == SRC_TEMP) {
         if (vclass(in.src_type) == C_BOOL) {
@@ -478,7 +497,7 @@ struct Interp {
         }
       }
       switch (in.op) {
-        case OP_LOAD:
+        case OP_LOAD:   // constant or temporary
 #pragma unroll
           for (int j = 0; j < R; ++j) lo[j] = bl[j];
 #pragma unroll
@@ -575,13 +594,16 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE>&) {});
     const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
     s_sel[buf][tid] = selv;
-    unsigned cnt = 0;
+    if (p.sel_mask) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const u64 m = __ballot((selv >> j) & 1);
-      if (p.sel_mask && lane == 0 && it.w0 + 64 * j < p.nrows) p.sel_mask[(it.w0 >> 6) + j] = m;
-      cnt += __popcll(m);
+      for (int j = 0; j < R; ++j) {
+        const u64 m = __ballot((selv >> j) & 1);
+        if (lane == 0 && it.w0 + 64 * j < p.nrows) p.sel_mask[(it.w0 >> 6) + j] = m;
+      }
     }
+    unsigned cnt = __popc(selv);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if (lane == 0) s_wave_cnt[buf][wv] = cnt;
     __syncthreads();
     if (wv == 0) {
@@ -644,7 +666,36 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         switch (oc.width) {
           case 1: COPY_COL(uint8_t, R) break;
           case 2: COPY_COL(uint16_t, R) break;
-          case 4: COPY_COL(uint32_t, R) break;
+          case 4: {
+            // runs of 4-byte columns are software-pipelined: the loads of the next column are issued before the
+            // stores of the current one, so the CU always has loads in flight
+            int cl = c;
+            while (cl + 1 < ncopy && p.outs[cl + 1].width == 4) ++cl;
+            uint32_t va[R], vb[R];
+            auto ld = [&](int k, uint32_t (&v)[R]) {
+              const uint32_t* src = (const uint32_t*)p.outs[k].in + w0;
+#pragma unroll
+              for (int j = 0; j < R; ++j) v[j] = src[LOAD_IDX(j)];
+            };
+            auto st = [&](int k, const uint32_t (&v)[R]) {
+              uint32_t* dst = (uint32_t*)p.outs[k].out + off0;
+              unsigned run = 0;
+#pragma unroll
+              for (int j = 0; j < R; ++j) {
+                const bool sel = (selv >> j) & 1;
+                const u64 m = __ballot(sel);
+                if (sel) dst[run + lane_rank(m)] = v[j];
+                run += __popcll(m);
+              }
+            };
+            ld(c, va);
+            for (int k = c; k <= cl; k += 2) {
+              if (k + 1 <= cl) ld(k + 1, vb);
+              st(k, va);
+              if (k + 1 <= cl) { if (k + 2 <= cl) ld(k + 2, va); st(k + 1, vb); }
+            }
+            c = cl;
+          } break;
           case 8: COPY_COL(uint2, (R >= 8 ? 8 : R)) break;
           default: {   // 16-byte values (decimal128 ...): named registers, a private array would be promoted to LDS
             const uint4* src = (const uint4*)oc.in + w0; uint4* dst = (uint4*)oc.out + off0; unsigned run = 0;

@@ -169,13 +169,17 @@ class DeviceRecordBatch:
     def from_device_pointers(columns: Sequence[Tuple[str, str, int]], num_rows: int, ctx: Optional[Context] = None,
                              keepalive=None) -> "DeviceRecordBatch":
         """Wrap caller-owned HBM buffers (e.g. torch tensors) without copying.
-        `columns`: (name, arrow_format, device_address_of_values) for non-null fixed-width columns."""
+        `columns`: (name, arrow_format, device_address_of_values[, device_address_of_utf8_bytes]) for non-null
+        columns; for Utf8 ("u") the values buffer holds the int32 offsets."""
         ctx = ctx or default_context()
         descs = (L.ColumnDesc * max(1, len(columns)))()
-        for i, (name, fmt, addr) in enumerate(columns):
+        for i, col in enumerate(columns):
+            name, fmt, addr = col[0], col[1], col[2]
             descs[i].name = name.encode()
             descs[i].format = fmt.encode()
             descs[i].values = addr
+            if len(col) > 3:
+                descs[i].data = col[3]
         out = _CBatch()
         rc = L.lib().chq_wrap_columns(ctx.handle, descs, len(columns), num_rows, L.ARROW_DEVICE_ROCM, C.byref(out.array), C.byref(out.schema))
         if rc:
