@@ -106,11 +106,12 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return CHQ_ERR_INVALID_HANDLE;
   return guarded(ctx, [&] {
     std::string k(key);
-    if (k == "tile_kind") { if (value < -1 || value > 4) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "tile_kind must be -1..4"}; ctx->c.opt_tile_kind = value; }
+    if (k == "tile_kind") { if (value < -1 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "tile_kind must be -1..2"}; ctx->c.opt_tile_kind = value; }
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
     else if (k == "debug") ctx->c.opt_debug = value;
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
+    else if (k == "split_rows") ctx->c.opt_split_rows = value;
     else if (k == "trim_pool") DevicePool::instance().trim();
     else throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "unknown option: " + k};
   });

@@ -98,6 +98,8 @@ struct ProgramBlock {
 
 struct FilterParams {
   int64_t nrows;          // rows the mask covers
+  int64_t tile_begin;     // this launch handles tiles [tile_begin, tile_end); the tail tile of a batch (the only one
+  int64_t tile_end;       // that can be partial) runs in its own launch of the PARTIAL instantiation
   u64* status;       // per tile: flag(2) | value(62); zeroed before launch
   uint32_t* ticket;       // zeroed before launch
   u64* total;        // out: number of selected rows
@@ -112,6 +114,7 @@ struct FilterParams {
 
 struct ProjectParams {
   int64_t nrows;
+  int64_t tile_begin, tile_end;
   u64* err;
   int32_t n_proj;
   int32_t pad;

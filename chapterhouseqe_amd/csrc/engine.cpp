@@ -358,8 +358,8 @@ std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* al
 // =================================================================================================
 namespace {
 
-constexpr int64_t kTileRows[5] = {1024 * 16, 256 * 8, 256 * 8, 512 * 16, 256 * 16};
-constexpr int kGridPerCu[5] = {1, 4, 4, 2, 4};
+constexpr int64_t kTileRows[3] = {1024 * 16, 256 * 8, 256 * 8};
+constexpr int kGridPerCu[3] = {1, 4, 4};
 
 struct Scratch {   // layout of ctx.small (device) and ctx.pinned (host mirror)
   uint32_t ticket; uint32_t pad0;
@@ -551,10 +551,25 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     p.debug = (int32_t)ctx.opt_debug;
     check_hip(hipMemsetAsync(ctx.status->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset status");
     check_hip(hipMemsetAsync(ds, 0, 16, ctx.stream), "memset scratch");
+    check_hip(hipMemsetAsync(&ds->ticket2, 0, 8, ctx.stream), "memset scratch");
     if (first) check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
     const int kind = first ? tile_kind : (tile_kind == 2 ? 1 : tile_kind);   // kinds 1 and 2 share a tile size
     if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev0, ctx.stream), "hipEventRecord");
-    check_hip(launch_filter(p, kind, grid, ctx.stream), "launch filter_fused_kernel");
+    // Large batches: all complete tiles run in the instantiation that contains no partial-tile code at all; the
+    // (single) incomplete tail tile runs in a second one-workgroup launch that continues the same chained scan.
+    const int64_t nfull = mask_len / tile_rows;
+    if (mask_len >= ctx.opt_split_rows && nfull > 0) {
+      p.tile_begin = 0; p.tile_end = nfull;
+      check_hip(launch_filter(p, kind, false, (int)std::min<int64_t>(nfull, grid_cap), ctx.stream), "launch filter_fused_kernel");
+      if (nfull < ntiles) {
+        p.tile_begin = nfull; p.tile_end = ntiles; p.ticket = &ds->ticket2;
+        check_hip(launch_filter(p, kind, true, 1, ctx.stream), "launch filter_fused_kernel (tail)");
+        ++ctx.stats.launches;
+      }
+    } else {
+      p.tile_begin = 0; p.tile_end = ntiles;
+      check_hip(launch_filter(p, kind, true, grid, ctx.stream), "launch filter_fused_kernel");
+    }
     if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev1, ctx.stream), "hipEventRecord");
     ++ctx.stats.launches;
     first = false;
@@ -755,8 +770,20 @@ std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::ve
     check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
     const int tile_kind = pick_tile_kind(ctx, lw, nrows);
     const int64_t ntiles = (nrows + kTileRows[tile_kind] - 1) / kTileRows[tile_kind];
-    const int grid = (int)std::min<int64_t>(ntiles, tile_kind == 0 ? (int64_t)ctx.num_cus * 2 : (int64_t)ctx.num_cus * 8);
-    check_hip(launch_project(p, tile_kind, grid, ctx.stream), "launch project_kernel");
+    const int64_t gcap = tile_kind == 0 ? (int64_t)ctx.num_cus * 2 : (int64_t)ctx.num_cus * 8;
+    const int64_t nfull = nrows / kTileRows[tile_kind];
+    if (nrows >= ctx.opt_split_rows && nfull > 0) {
+      p.tile_begin = 0; p.tile_end = nfull;
+      check_hip(launch_project(p, tile_kind, false, (int)std::min<int64_t>(nfull, gcap), ctx.stream), "launch project_kernel");
+      if (nfull < ntiles) {
+        p.tile_begin = nfull; p.tile_end = ntiles;
+        check_hip(launch_project(p, tile_kind, true, 1, ctx.stream), "launch project_kernel (tail)");
+        ++ctx.stats.launches;
+      }
+    } else {
+      p.tile_begin = 0; p.tile_end = ntiles;
+      check_hip(launch_project(p, tile_kind, true, (int)std::min<int64_t>(ntiles, gcap), ctx.stream), "launch project_kernel");
+    }
     ++ctx.stats.launches;
     check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");

@@ -15,8 +15,8 @@
 namespace chq {
 
 // kernels.hip
-hipError_t launch_filter(const FilterParams& p, int tile_kind, int grid, hipStream_t stream);
-hipError_t launch_project(const ProjectParams& p, int tile_kind, int grid, hipStream_t stream);
+hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
+hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
@@ -94,6 +94,7 @@ struct Context {
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
   int64_t opt_grid_per_cu = 0;
+  int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
   int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // reusable device scratch

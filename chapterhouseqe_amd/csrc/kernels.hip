@@ -96,6 +96,16 @@ __device__ __forceinline__ u64 load_bits64(const void* bitmap, int64_t bitpos, u
   return r & act;
 }
 
+// same, for a group that lies completely inside the batch (no masking, no bit counting)
+__device__ __forceinline__ u64 load_bits64_full(const void* bitmap, int64_t bitpos) {
+  uint64_t abs = ((uint64_t)(uintptr_t)bitmap << 3) + (uint64_t)bitpos;
+  const u64* p = (const u64*)(uintptr_t)((abs >> 6) << 3);
+  int sh = (int)(abs & 63);
+  u64 r = p[0] >> sh;
+  if (sh != 0) r |= p[1] << (64 - sh);
+  return r;
+}
+
 __device__ __forceinline__ int32_t f32_key(uint32_t b) { int32_t s = (int32_t)b; return s ^ (int32_t)(((uint32_t)(s >> 31)) >> 1); }
 __device__ __forceinline__ int64_t f64_key(uint64_t b) { int64_t s = (int64_t)b; return s ^ (int64_t)(((uint64_t)(s >> 63)) >> 1); }
 
@@ -132,7 +142,8 @@ __device__ __forceinline__ void int_range(int t, int64_t& lo, int64_t& hi) {
 // boolean AND/OR over all R rows is one VALU op.  All arrays are indexed with compile-time constants
 // only (loops fully unrolled) so they live in VGPRs.  WIDE=false instantiations carry no 64-bit types.
 // ------------------------------------------------------------------------------------------------
-template <int BLOCK, int R, bool WIDE>
+// PARTIAL=false: every wave has all 64*R rows inside the batch (no clamping / masking code is generated at all)
+template <int BLOCK, int R, bool WIDE, bool PARTIAL>
 struct Interp {
   static constexpr int NW = BLOCK / 64;
   static constexpr int RH = WIDE ? R : 1;
@@ -149,10 +160,12 @@ struct Interp {
   __device__ __forceinline__ void set_rows(int64_t tile_start, int64_t nrows_, int lane_, int wv_) {
     lane = lane_; wv = wv_; nrows = nrows_;
     w0 = tile_start + (int64_t)wv * 64 * R;
-    int64_t rem = nrows - w0;
-    nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
-    if (nact == 64 * R) actv = R == 32 ? 0xffffffffu : ((1u << R) - 1u);
-    else {
+    if constexpr (!PARTIAL) {
+      nact = 64 * R;
+      actv = R == 32 ? 0xffffffffu : ((1u << R) - 1u);
+    } else {
+      int64_t rem = nrows - w0;
+      nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
       actv = 0;
 #pragma unroll
       for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
@@ -168,7 +181,9 @@ struct Interp {
     uint32_t f = 0;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      u64 wd = load_bits64(bitmap, bit_offset + w0 + 64 * j, group_act(j));
+      u64 wd;
+      if constexpr (PARTIAL) wd = load_bits64(bitmap, bit_offset + w0 + 64 * j, group_act(j));
+      else wd = load_bits64_full(bitmap, bit_offset + w0 + 64 * j);
       f |= (uint32_t)((wd >> lane) & 1) << j;
     }
     return f;
@@ -207,8 +222,10 @@ struct Interp {
 
   __device__ __forceinline__ void fetch_col(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
     b = 0;
-    if (nact == 64 * R && c.type != T_BOOL) fetch_values<true>(c, l, h);
-    else {
+    if constexpr (!PARTIAL) {
+      if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
+      else fetch_values<true>(c, l, h);
+    } else {
 #pragma unroll
       for (int j = 0; j < R; ++j) l[j] = 0;
 #pragma unroll
@@ -569,7 +586,7 @@ struct TempLds {
 // successors' look-backs need it.  Everything a wave derives from the tile index / tile base goes through
 // readfirstlane so that global accesses are SGPR-base + 32-bit lane offset.
 // ------------------------------------------------------------------------------------------------
-template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL>
 __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams p) {
   constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
@@ -582,16 +599,17 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
+  const int64_t ntiles = p.tile_end;                       // this launch: tiles [tile_begin, tile_end)
+  const int64_t last_tile = (p.nrows + TILE - 1) / TILE - 1;   // of the whole batch
 
   auto P = [&](int buf) {
-    if (tid == 0) s_tile[buf] = (int64_t)atomicAdd(p.ticket, 1u);
+    if (tid == 0) s_tile[buf] = p.tile_begin + (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const int64_t tile = uniform64(s_tile[buf]);
     if (tile >= ntiles) return;
-    Interp<BLOCK, R, WIDE> it;
+    Interp<BLOCK, R, WIDE, PARTIAL> it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
-    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE>&) {});
+    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE, PARTIAL>&) {});
     const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
     s_sel[buf][tid] = selv;
     if (p.sel_mask) {
@@ -625,16 +643,19 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         excl = lookback_exclusive(p.status, tile, 0, lane);
         if (lane == 0) st_store(&p.status[tile], ST_INC | (excl + s_tot[buf]));
       }
-      if (lane == 0) { s_base = excl; if (tile == ntiles - 1) *p.total = (p.debug & 1) ? (u64)p.nrows : excl + s_tot[buf]; }
+      if (lane == 0) { s_base = excl; if (tile == last_tile) *p.total = (p.debug & 1) ? (u64)p.nrows : excl + s_tot[buf]; }
     }
     __syncthreads();
     u64 off0 = s_base;
     for (int w = 0; w < wv; ++w) off0 += s_wave_cnt[buf][w];
     off0 = (u64)uniform64((int64_t)off0);
     const int64_t w0 = tile * TILE + (int64_t)wv * 64 * R;
-    const int64_t rem = p.nrows - w0;
-    const int nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
-    if (nact <= 0) return;
+    int nact = 64 * R;
+    if constexpr (PARTIAL) {
+      const int64_t rem = p.nrows - w0;
+      nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
+      if (nact <= 0) return;
+    }
     const uint32_t selv = s_sel[buf][tid];
     if (p.grp_base) {
       u64 run = off0;
@@ -716,7 +737,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 #undef LOAD_IDX
       }
     };
-    if (nact == 64 * R) copy_columns(std::true_type{}); else copy_columns(std::false_type{});
+    copy_columns(std::integral_constant<bool, !PARTIAL>{});
   };
 
   P(0);
@@ -733,18 +754,17 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 // ------------------------------------------------------------------------------------------------
 // project_kernel: evaluate every SelectItem expression densely (no compaction, no inter-tile state)
 // ------------------------------------------------------------------------------------------------
-template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL>
 __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
   constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
   __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    Interp<BLOCK, R, WIDE> it;
+  for (int64_t tile = p.tile_begin + blockIdx.x; tile < p.tile_end; tile += gridDim.x) {
+    Interp<BLOCK, R, WIDE, PARTIAL> it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
-    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [&](int out_idx, int acc_type, Interp<BLOCK, R, WIDE>& s) {
+    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [&](int out_idx, int acc_type, Interp<BLOCK, R, WIDE, PARTIAL>& s) {
       const ProjOut po = p.outs[out_idx];
       if (s.nact <= 0) return;
       const int cls = vclass(acc_type);
@@ -950,22 +970,27 @@ __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
 // tile_kind 0: 1024 threads x 16 rows, 32-bit types only, no numeric temporaries (the streaming path)
 // tile_kind 1:  256 threads x  8 rows, 32-bit types only
 // tile_kind 2:  256 threads x  8 rows, all types, numeric temporaries in LDS (general path)
-hipError_t launch_filter(const FilterParams& p, int tile_kind, int grid, hipStream_t stream) {
+// partial: the launch may contain a tile that is not completely inside the batch
+hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
+#define LF(B, RR, W, T) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, true>), dim3(grid), dim3(B), 0, stream, p); \
+                             else hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, false>), dim3(grid), dim3(B), 0, stream, p); } while (0)
   switch (tile_kind) {
-    case 0: hipLaunchKernelGGL((filter_fused_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
-    case 1: hipLaunchKernelGGL((filter_fused_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((filter_fused_kernel<512, 16, false, 0>), dim3(grid), dim3(512), 0, stream, p); break;
-    case 4: hipLaunchKernelGGL((filter_fused_kernel<256, 16, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL((filter_fused_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
+    case 0: LF(1024, 16, false, 0); break;
+    case 1: LF(256, 8, false, 0); break;
+    default: LF(256, 8, true, MAX_NUM_TEMPS); break;
   }
+#undef LF
   return hipGetLastError();
 }
-hipError_t launch_project(const ProjectParams& p, int tile_kind, int grid, hipStream_t stream) {
+hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
+#define LP(B, RR, W, T) do { if (partial) hipLaunchKernelGGL((project_kernel<B, RR, W, T, true>), dim3(grid), dim3(B), 0, stream, p); \
+                             else hipLaunchKernelGGL((project_kernel<B, RR, W, T, false>), dim3(grid), dim3(B), 0, stream, p); } while (0)
   switch (tile_kind) {
-    case 0: hipLaunchKernelGGL((project_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
-    case 1: hipLaunchKernelGGL((project_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL((project_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
+    case 0: LP(1024, 16, false, 0); break;
+    case 1: LP(256, 8, false, 0); break;
+    default: LP(256, 8, true, MAX_NUM_TEMPS); break;
   }
+#undef LP
   return hipGetLastError();
 }
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream) {

@@ -183,11 +183,16 @@ def test_fuzz_compute_value_vs_oracle(ctx, n):
     assert outcomes["ok"] >= 5, outcomes
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("tile_kind", [0, 1, 2])
 @pytest.mark.parametrize("n", [1, 2048, 16384, 16385, 40_000])
-def test_every_kernel_instantiation(n, tile_kind):
+def test_every_kernel_instantiation(n, tile_kind, split):
+    """split=True forces the large-batch launch structure (complete tiles in the FULL-only instantiation, the
+    incomplete tail tile in a second launch that continues the chained scan) on small inputs."""
     c = chq.Context(0)
     c.set_option("tile_kind", tile_kind)
+    if split:
+        c.set_option("split_rows", 1)
     rec = make_batch(n, 31 * n + tile_kind)
     al = empty_aliases(rec)
     for sql in ["f32 > 10.0", "i32 % 2 = 0 and u8 < 200", "flag or i16 * 2 > small", "k <> 'k3' and f32 / 3.0 < 20.0"]:

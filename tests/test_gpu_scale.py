@@ -51,7 +51,7 @@ def test_config2_full_size_against_torch(n, thr):
         assert int(exp.view(torch.int32).to(torch.int64).sum().item()) == int(g_.view(torch.int32).to(torch.int64).sum().item())
         del exp
     st = ctx.last_stats()
-    assert st["rows_in"] == n and st["rows_out"] == m and st["launches"] == 1
+    assert st["rows_in"] == n and st["rows_out"] == m and st["launches"] == (1 if n % 16384 == 0 else 2)   # + the tail-tile launch
     out.release()
     ctx.close()
 
