@@ -109,6 +109,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     if (k == "tile_kind") { if (value < -1 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "tile_kind must be -1..2"}; ctx->c.opt_tile_kind = value; }
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
+    else if (k == "stash") ctx->c.opt_stash = value != 0;
     else if (k == "debug") ctx->c.opt_debug = value;
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
     else if (k == "split_rows") ctx->c.opt_split_rows = value;

@@ -88,9 +88,17 @@ constexpr int MAX_NUM_TEMPS = 2;
 constexpr u64 ERR_NONE = ~0ULL;
 enum DevErr : uint32_t { DE_OVERFLOW = 1, DE_DIV_ZERO = 2 };
 
+// Specialised predicate shapes that bypass the interpreter loop (host sets `fast_kind` after lowering)
+enum FastKind : int32_t {
+  FAST_NONE = 0,
+  FAST_CMP_CONST = 1,   // refs[0] (Int32 / UInt32 / Float32, no nulls) <cmp prog[1].op> literal prog[1].imm, e.g. value2 > 10.0
+};
+
 struct ProgramBlock {
   int32_t n_instr;
   int32_t n_refs;
+  int32_t fast_kind;
+  int32_t pad;
   Instr prog[MAX_INSTR];
   ColRef refs[MAX_REFS];
   ConstStr strs[MAX_CONST_STR];
@@ -106,7 +114,9 @@ struct FilterParams {
   u64* err;          // ERR_NONE before launch
   u64* sel_mask;     // optional: selection bitmap (one u64 per 64 rows), for follow-up kernels
   u64* grp_base;     // optional: output row index of each 64-row group's first selected row
-  int32_t n_out;
+  int16_t n_out;
+  int16_t stash_ref;      // program column-ref whose raw tile values stay in LDS between P and C (-1: none); when set,
+                          // that column is outs[n_out - 1] and is copied from LDS instead of being fetched again
   int32_t debug;          // experiments only: bit0 = no inter-tile dependency (base = tile * TILE), bit1 = skip last column
   ProgramBlock pb;
   OutCol outs[MAX_OUT];

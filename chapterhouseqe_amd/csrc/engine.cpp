@@ -381,6 +381,15 @@ Scratch* dev_scratch(Context& ctx) { return (Scratch*)ctx.small->ptr; }
 void fill_refs(ProgramBlock& pb, const Lowered& lw, const Batch& rec, const std::vector<BufferPtr>& str_bufs) {
   pb.n_instr = (int32_t)lw.prog.size();
   pb.n_refs = (int32_t)lw.refs.size();
+  pb.fast_kind = FAST_NONE;
+  // [LOAD col:T] [CMP literal] on a non-null 32-bit column of exactly the compare type: specialised device path
+  if (lw.prog.size() == 2 && lw.refs.size() == 1 && lw.prog[0].op == OP_LOAD && lw.prog[0].src_kind == SRC_COL &&
+      lw.prog[0].src_type == lw.prog[0].type && lw.prog[1].op >= OP_EQ && lw.prog[1].op <= OP_GE &&
+      lw.prog[1].src_kind == SRC_CONST && lw.prog[1].type == lw.prog[0].type &&
+      (lw.prog[0].type == T_I32 || lw.prog[0].type == T_U32 || lw.prog[0].type == T_F32)) {
+    const Column& c0 = rec.cols[lw.refs[0]];
+    if (!(c0.validity && c0.null_count != 0)) pb.fast_kind = FAST_CMP_CONST;
+  }
   for (size_t i = 0; i < lw.prog.size(); ++i) pb.prog[i] = lw.prog[i];
   for (size_t i = 0; i < lw.refs.size(); ++i) {
     const Column& c = rec.cols[lw.refs[i]];
@@ -541,13 +550,24 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       p.pb.prog[0] = in;
       ColRef r{}; r.values = sel_mask->ptr; r.type = T_BOOL; p.pb.refs[0] = r;
     }
+    std::vector<int> launch_cols;
+    while (next_fixed < fixed_cols.size() && (int)launch_cols.size() < MAX_OUT) launch_cols.push_back(fixed_cols[next_fixed++]);
+    // keep one narrow predicate input column on chip between the predicate and copy phases (placed last)
+    p.stash_ref = -1;
+    if (first && ctx.opt_stash) {
+      for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
+        const Column& c = rec.cols[lw.refs[r]];
+        if (c.type == T_BOOL || c.type == T_UTF8 || c.width > 4) continue;
+        auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
+        if (it != launch_cols.end()) { launch_cols.erase(it); launch_cols.push_back(lw.refs[r]); p.stash_ref = (int16_t)r; }
+      }
+    }
     int n = 0;
-    while (next_fixed < fixed_cols.size() && n < MAX_OUT) {
-      const int ci = fixed_cols[next_fixed++];
+    for (int ci : launch_cols) {
       p.outs[n].in = rec.cols[ci].values0(); p.outs[n].out = (void*)out.cols[ci].values; p.outs[n].width = (uint32_t)rec.cols[ci].width;
       ++n;
     }
-    p.n_out = n;
+    p.n_out = (int16_t)n;
     p.debug = (int32_t)ctx.opt_debug;
     check_hip(hipMemsetAsync(ctx.status->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset status");
     check_hip(hipMemsetAsync(ds, 0, 16, ctx.stream), "memset scratch");

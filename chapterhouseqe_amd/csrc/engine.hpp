@@ -93,6 +93,7 @@ struct Context {
   int64_t opt_tile_kind = -1;       // -1 auto
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
+  bool opt_stash = true;
   int64_t opt_grid_per_cu = 0;
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
   int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
