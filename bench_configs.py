@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
 
     import numpy as np
@@ -36,6 +37,9 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     ctx.set_option("time_kernels", 1)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     results = []
 
     def gen(n, spec, seed):

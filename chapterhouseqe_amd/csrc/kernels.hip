@@ -803,6 +803,17 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     }
   };
 
+  if (p.debug & 8) {
+    // non-pipelined order: C(i) follows P(i) immediately, so the copy phase re-reads the predicate's input columns
+    // while they are still in L2 / Infinity Cache; the look-back wait is exposed instead
+    while (true) {
+      P(0);
+      if (s_tile[0] >= ntiles) break;
+      C(0);
+      __syncthreads();
+    }
+    return;
+  }
   P(0);
   int itn = 0;
   while (true) {
@@ -939,7 +950,7 @@ __global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p)
     const int64_t tile = s_tile;
     if (tile >= ntiles) break;
     const int64_t w0 = tile * TILE + (int64_t)wv * 64 * G;
-    u64 len[G]; u64 msk[G];
+    uint32_t len[G]; u64 msk[G];     // a row is < 2 GiB (int32 offsets): 32-bit lengths, 64-bit totals
     u64 bytes = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -947,7 +958,7 @@ __global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p)
       const u64 act = active_mask(r0, p.nrows);
       msk[g] = act ? (p.sel_mask[r0 >> 6] & act) : 0ULL;
       len[g] = 0;
-      if ((msk[g] >> lane) & 1) { const int32_t* o = p.in_offsets + r0 + lane; len[g] = (u64)(o[1] - o[0]); }
+      if ((msk[g] >> lane) & 1) { const int32_t* o = p.in_offsets + r0 + lane; len[g] = (uint32_t)(o[1] - o[0]); }
       bytes += len[g];
     }
     bytes = wave_sum(bytes);
@@ -974,9 +985,9 @@ __global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p)
     for (int g = 0; g < G; ++g) {
       const int64_t r0 = w0 + 64 * g;
       if (msk[g]) {
-        u64 inc = len[g];
+        uint32_t inc = len[g];   // a 64-row group stays below 2^32 bytes only if rows do: guard with the 64-bit total
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { u64 t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
         if ((msk[g] >> lane) & 1) p.out_offsets[p.grp_base[r0 >> 6] + lane_rank(msk[g])] = (int32_t)(boff + inc - len[g]);
         boff += __shfl(inc, 63, 64);
       }
@@ -985,9 +996,20 @@ __global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p)
   }
 }
 
-// Utf8 filter, kernel 2: copy the bytes of the selected rows. One wave per 64 rows: the selected rows
-// of the group are contiguous in the output, each is copied by the whole wave (coalesced for the
-// >= 64 B strings of the wide-string data set; short strings are handled lane-per-row).
+// Utf8 filter, kernel 2: copy the bytes of the selected rows.  One wave per 64 rows; the selected rows of a group
+// are contiguous in the output.  Bytes move in 4-byte chunks (global memory takes unaligned dword accesses), the
+// 0-3 trailing bytes of a row one at a time.  Long strings (the 100-character wide-string data set) are copied by
+// half a wave per row, two rows per instruction; short strings by one lane per row.
+__device__ __forceinline__ void copy_row_chunks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int len, int first, int step) {
+  for (int b = first * 4; b + 4 <= len; b += step * 4) {
+    uint32_t w;
+    __builtin_memcpy(&w, src + b, 4);
+    __builtin_memcpy(dst + b, &w, 4);
+  }
+  const int tail = len & ~3;
+  if (first < (len & 3)) dst[tail + first] = src[tail + first];
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
   constexpr int NW = BLOCK / 64;
@@ -1002,26 +1024,34 @@ __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
     int32_t s0 = 0, s1 = 0;
     if (sel) { const int32_t* o = p.in_offsets + r0 + lane; s0 = o[0]; s1 = o[1]; }
     const int cnt = __popcll(m);
-    const unsigned dst = sel ? lane_rank(m) : 63u - lane_rank(~m);
+    const unsigned dstl = sel ? lane_rank(m) : 63u - lane_rank(~m);
     // lane k now describes the selected row of rank k
-    const int src0 = __builtin_amdgcn_ds_permute((int)(dst << 2), s0);
-    const int len0 = __builtin_amdgcn_ds_permute((int)(dst << 2), s1 - s0);
+    const int src0 = __builtin_amdgcn_ds_permute((int)(dstl << 2), s0);
+    const int len0 = __builtin_amdgcn_ds_permute((int)(dstl << 2), s1 - s0);
     const int64_t dbase = p.out_offsets[p.grp_base[g]];   // bytes of this group are contiguous in the output
-    // exclusive prefix of the lengths = destination of each row relative to dbase
     int inc = lane < cnt ? len0 : 0;
     const int mylen = inc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     const int dst0 = inc - mylen;
     const int group_bytes = __shfl(inc, 63, 64);
-    const int maxlen = group_bytes;  // upper bound used only to pick a strategy
-    if (maxlen <= 64 * 16) {
-      // short strings: lane per row
-      if (lane < cnt) for (int b = 0; b < mylen; ++b) p.out_data[dbase + dst0 + b] = p.in_data[(int64_t)src0 + b];
+    if (group_bytes <= cnt * 24) {
+      // short strings: one lane per row
+      if (lane < cnt) {
+        const uint8_t* src = p.in_data + src0;
+        uint8_t* dst = p.out_data + dbase + dst0;
+        int b = 0;
+        for (; b + 4 <= mylen; b += 4) { uint32_t w; __builtin_memcpy(&w, src + b, 4); __builtin_memcpy(dst + b, &w, 4); }
+        for (; b < mylen; ++b) dst[b] = src[b];
+      }
     } else {
-      for (int k = 0; k < cnt; ++k) {
-        const int s = __shfl(src0, k, 64), l = __shfl(len0, k, 64), d = __shfl(dst0, k, 64);
-        for (int b = lane; b < l; b += 64) p.out_data[dbase + d + b] = p.in_data[(int64_t)s + b];
+      // long strings: half a wave per row, two rows per step
+      const int half = lane >> 5, hl = lane & 31;
+      for (int k = 0; k < cnt; k += 2) {
+        const int r = k + half;
+        const int rr = r < cnt ? r : cnt - 1;
+        const int sr = __shfl(src0, rr, 64), lr = __shfl(len0, rr, 64), dr = __shfl(dst0, rr, 64);
+        if (r < cnt) copy_row_chunks(p.in_data + sr, p.out_data + dbase + dr, lr, hl, 32);
       }
     }
   }
