@@ -368,6 +368,7 @@ struct Scratch {   // layout of ctx.small (device) and ctx.pinned (host mirror)
   unsigned long long total_bytes;
   uint32_t ticket2; uint32_t pad1;
   unsigned long long counters[24];
+  int32_t utf8_ends[16];   // host mirror only: first / last input offset of each Utf8 column (output byte capacity)
 };
 
 void ensure_scratch(Context& ctx, int64_t ntiles) {
@@ -597,6 +598,12 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
 
   Scratch* hs = (Scratch*)ctx.pinned;
   check_hip(hipMemcpyAsync(hs, ds, 32, hipMemcpyDeviceToHost, ctx.stream), "read back");
+  if (utf8_cols.size() > 8) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 8 Utf8 columns in one batch"};
+  for (size_t k = 0; k < utf8_cols.size(); ++k) {   // input byte span of every Utf8 column = capacity of its output
+    const int32_t* offs = (const int32_t*)rec.cols[utf8_cols[k]].values0();
+    check_hip(hipMemcpyAsync(&hs->utf8_ends[2 * k], offs, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
+    check_hip(hipMemcpyAsync(&hs->utf8_ends[2 * k + 1], offs + mask_len, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
+  }
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
   if (hs->err != ERR_NONE) throw_device_error(hs->err);
@@ -630,50 +637,47 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       auto ob = bit_compact(rec.cols[ci].validity, rec.cols[ci].offset, &ds->counters[k]);
       out.cols[ci].validity = (const uint8_t*)ob->ptr; out.cols[ci].owned.push_back(ob);
     }
-    // ---- Utf8 columns: offsets, then bytes -----------------------------------------------------------
+    // ---- Utf8 columns: one fused pass each (new offsets + bytes) --------------------------------------
+    // Short strings: one fused pass (new offsets + bytes, 8192-row tiles).  Long strings: offsets pass (2048-row
+    // tiles) then a copy pass with one wave per 64 rows, which spreads the byte copies over far more waves.
     std::vector<BufferPtr> byte_status(utf8_cols.size());
-    std::vector<Utf8Params> ups(utf8_cols.size());
-    if (utf8_cols.size() > 8) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 8 Utf8 columns in one batch"};
-    const int64_t utiles = (mask_len + 2047) / 2048;
     for (size_t k = 0; k < utf8_cols.size(); ++k) {
       const int ci = utf8_cols[k];
       const Column& c = rec.cols[ci];
       Column& o = out.cols[ci];
+      const int64_t cap = (int64_t)hs->utf8_ends[2 * k + 1] - hs->utf8_ends[2 * k];
+      const bool fused = cap <= mask_len * 24;
+      const int64_t utiles = (mask_len + (fused ? 8191 : 2047)) / (fused ? 8192 : 2048);
       auto offb = make_device_buffer((size_t)(total + 2) * 4, ctx.device);
+      auto db = make_device_buffer((size_t)cap + 16, ctx.device);
       byte_status[k] = make_device_buffer((size_t)(utiles + 64) * 8 + 16, ctx.device);
       check_hip(hipMemsetAsync(byte_status[k]->ptr, 0, (size_t)(utiles + 64) * 8 + 16, ctx.stream), "memset");
       Utf8Params up{};
       up.nrows = mask_len; up.sel_mask = (const u64*)sel_mask->ptr; up.grp_base = (const u64*)grp_base->ptr;
       up.in_offsets = (const int32_t*)c.values0(); up.in_data = c.data;
-      up.out_offsets = (int32_t*)offb->ptr; up.out_data = nullptr;
+      up.out_offsets = (int32_t*)offb->ptr; up.out_data = (uint8_t*)db->ptr;
       up.byte_status = (u64*)byte_status[k]->ptr;
       up.ticket = (uint32_t*)((uint8_t*)byte_status[k]->ptr + (size_t)(utiles + 64) * 8);
       up.total_bytes = &ds->counters[16 + k];   // counters[16..23] reserved for byte totals
       up.rows_out = total;
-      ups[k] = up;
-      check_hip(launch_utf8_offsets(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 8), ctx.stream), "launch utf8_offsets_kernel");
-      ++ctx.stats.launches;
+      if (fused) {
+        check_hip(launch_utf8_filter(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 2), ctx.stream), "launch utf8_filter_kernel");
+        ++ctx.stats.launches;
+      } else {
+        check_hip(launch_utf8_offsets(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 8), ctx.stream), "launch utf8_offsets_kernel");
+        check_hip(launch_utf8_copy(up, (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx.num_cus * 16), ctx.stream), "launch utf8_copy_kernel");
+        ctx.stats.launches += 2;
+      }
       o.values = (const uint8_t*)offb->ptr; o.owned.push_back(offb); o.length = total;
+      o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
     }
-    check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
+    check_hip(hipMemcpyAsync(hs, ds, 40 + sizeof(ds->counters), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
     for (size_t k = 0; k < nullable_cols.size(); ++k) {
       Column& o = out.cols[nullable_cols[k]];
       o.null_count = (int64_t)hs->counters[k];
       if (o.null_count == 0) o.validity = nullptr;   // arrow drops an all-valid null buffer
     }
-    for (size_t k = 0; k < utf8_cols.size(); ++k) {
-      Column& o = out.cols[utf8_cols[k]];
-      const int64_t nb = (int64_t)hs->counters[16 + k];
-      auto db = make_device_buffer((size_t)nb + 16, ctx.device);
-      ups[k].out_data = (uint8_t*)db->ptr;
-      o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
-      if (nb > 0) {
-        check_hip(launch_utf8_copy(ups[k], (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx.num_cus * 16), ctx.stream), "launch utf8_copy_kernel");
-        ++ctx.stats.launches;
-      }
-    }
-    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   }
   for (Column& o : out.cols) o.length = total;
   return out;

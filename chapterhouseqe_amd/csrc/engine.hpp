@@ -18,6 +18,7 @@ namespace chq {
 hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
+hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
 

@@ -931,6 +931,122 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactPara
 }
 
 // ------------------------------------------------------------------------------------------------
+// utf8_filter_kernel: arrow-select filter of a Utf8 column in one pass.  Tile = 64*G*NW rows.
+//   pass 1: every lane loads the offset of its row (coalesced), lengths of the selected rows come from the
+//           neighbour lane; wave / tile byte totals
+//   chained scan over the tiles' byte totals (same look-back as the row scan)
+//   pass 2: per 64-row group: exclusive scan of the lengths -> new offsets (written at the group's output row
+//           position, known from the main kernel's grp_base), then the bytes are copied in 4-byte chunks: one lane
+//           per row for short strings, half a wave per row for long ones
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void copy_row_chunks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int len, int first, int step) {
+  for (int b = first * 4; b + 4 <= len; b += step * 4) {
+    uint32_t w;
+    __builtin_memcpy(&w, src + b, 4);
+    __builtin_memcpy(dst + b, &w, 4);
+  }
+  const int tail = len & ~3;
+  if (first < (len & 3)) dst[tail + first] = src[tail + first];
+}
+
+template <int BLOCK, int G>
+__global__ __launch_bounds__(BLOCK) void utf8_filter_kernel(const Utf8Params p) {
+  constexpr int NW = BLOCK / 64;
+  constexpr int64_t TILE = (int64_t)64 * G * NW;
+  __shared__ u64 s_wave_bytes[NW];
+  __shared__ u64 s_base_bytes;
+  __shared__ int64_t s_tile;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
+  while (true) {
+    if (tid == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const int64_t tile = uniform64(s_tile);
+    if (tile >= ntiles) break;
+    const int64_t w0 = tile * TILE + (int64_t)wv * 64 * G;
+    int32_t src[G]; uint32_t len[G]; u64 msk[G];
+    u64 bytes = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int64_t r0 = w0 + 64 * g;
+      const u64 act = active_mask(r0, p.nrows);
+      msk[g] = act ? (p.sel_mask[r0 >> 6] & act) : 0ULL;
+      src[g] = 0; len[g] = 0;
+      if (msk[g]) {   // uniform
+        const int64_t last = p.nrows - r0 < 64 ? p.nrows - r0 : 64;             // offsets r0 .. r0+last are valid
+        const int32_t o = p.in_offsets[r0 + (lane < last ? lane : last)];
+        const int32_t oend = p.in_offsets[r0 + last];                            // broadcast load
+        int32_t nxt = __shfl_down(o, 1, 64);
+        if (lane + 1 >= last) nxt = oend;
+        src[g] = o;
+        len[g] = ((msk[g] >> lane) & 1) ? (uint32_t)(nxt - o) : 0u;
+      }
+      bytes += len[g];
+    }
+    bytes = wave_sum(bytes);
+    if (lane == 0) s_wave_bytes[wv] = bytes;
+    __syncthreads();
+    if (wv == 0) {
+      u64 tb = 0;
+      for (int w = 0; w < NW; ++w) tb += s_wave_bytes[w];
+      u64 excl = 0;
+      if (lane == 0) st_store(&p.byte_status[tile], (tile == 0 ? ST_INC : ST_AGG) | tb);
+      if (tile > 0) {
+        excl = lookback_exclusive(p.byte_status, tile, 0, lane);
+        if (lane == 0) st_store(&p.byte_status[tile], ST_INC | (excl + tb));
+      }
+      if (lane == 0) {
+        s_base_bytes = excl;
+        if (tile == ntiles - 1) { *p.total_bytes = excl + tb; p.out_offsets[p.rows_out] = (int32_t)(excl + tb); }
+      }
+    }
+    __syncthreads();
+    u64 boff = s_base_bytes;
+    for (int w = 0; w < wv; ++w) boff += s_wave_bytes[w];
+    boff = (u64)uniform64((int64_t)boff);
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      if (!msk[g]) continue;
+      const bool sel = (msk[g] >> lane) & 1;
+      uint32_t inc = len[g];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+      const uint32_t dsto = inc - len[g];                       // byte position of this row inside the group's output
+      const uint32_t group_bytes = __shfl(inc, 63, 64);
+      const int cnt = __popcll(msk[g]);
+      if (sel) p.out_offsets[p.grp_base[(w0 >> 6) + g] + lane_rank(msk[g])] = (int32_t)(boff + dsto);
+      uint8_t* gdst = p.out_data + boff;
+      if (group_bytes <= (uint32_t)cnt * 24u) {
+        if (sel) {   // short strings: one lane per row
+          const uint8_t* sp = p.in_data + src[g];
+          uint8_t* dp = gdst + dsto;
+          const int l = (int)len[g];
+          int b = 0;
+          for (; b + 4 <= l; b += 4) { uint32_t w; __builtin_memcpy(&w, sp + b, 4); __builtin_memcpy(dp + b, &w, 4); }
+          for (; b < l; ++b) dp[b] = sp[b];
+        }
+      } else {
+        // long strings: bring (src, len, dst) of the selected rows into rank order, half a wave per row
+        const unsigned dl = sel ? lane_rank(msk[g]) : 63u - lane_rank(~msk[g]);
+        const int rs = __builtin_amdgcn_ds_permute((int)(dl << 2), src[g]);
+        const int rl = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)len[g]);
+        const int rd = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)dsto);
+        const int half = lane >> 5, hl = lane & 31;
+        for (int k = 0; k < cnt; k += 2) {
+          const int r = k + half;
+          const int rr = r < cnt ? r : cnt - 1;
+          const int sr = __shfl(rs, rr, 64), lr = __shfl(rl, rr, 64), dr = __shfl(rd, rr, 64);
+          if (r < cnt) copy_row_chunks(p.in_data + sr, gdst + dr, lr, hl, 32);
+        }
+      }
+      boff += group_bytes;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Utf8 filter, kernel 1: byte length of every selected row -> new offsets.  A chained scan over tiles
 // of 64*G*NW rows carries the running byte total; row positions come from grp_base.
 // ------------------------------------------------------------------------------------------------
@@ -1000,16 +1116,6 @@ __global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p)
 // are contiguous in the output.  Bytes move in 4-byte chunks (global memory takes unaligned dword accesses), the
 // 0-3 trailing bytes of a row one at a time.  Long strings (the 100-character wide-string data set) are copied by
 // half a wave per row, two rows per instruction; short strings by one lane per row.
-__device__ __forceinline__ void copy_row_chunks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int len, int first, int step) {
-  for (int b = first * 4; b + 4 <= len; b += step * 4) {
-    uint32_t w;
-    __builtin_memcpy(&w, src + b, 4);
-    __builtin_memcpy(dst + b, &w, 4);
-  }
-  const int tail = len & ~3;
-  if (first < (len & 3)) dst[tail + first] = src[tail + first];
-}
-
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
   constexpr int NW = BLOCK / 64;
@@ -1090,7 +1196,11 @@ hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t s
   hipLaunchKernelGGL((bit_compact_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
-hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream) {
+hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream) {   // 8192-row tiles
+  hipLaunchKernelGGL((utf8_filter_kernel<1024, 8>), dim3(grid), dim3(1024), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream) {   // 2048-row tiles
   hipLaunchKernelGGL((utf8_offsets_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
