@@ -83,9 +83,12 @@ constexpr int MAX_CONST_STR = 4;
 constexpr int MAX_BOOL_TEMPS = 4;
 constexpr int MAX_NUM_TEMPS = 2;
 
-// error word, combined with atomicMin so the reference's "first error wins" order is reproduced:
+// error word: the device keeps the bitwise complement of
 //   [63:56] position of the node in the reference's evaluation order, [55:8] row index, [7:0] code
-constexpr u64 ERR_NONE = ~0ULL;
+// and combines reports with atomicMax, so the smallest (earliest node, then earliest row) wins -- the reference's
+// "first error ends the batch" order -- and "no error" is 0, i.e. the word is cleared by the same memset as the
+// rest of the scratch block.
+constexpr u64 ERR_NONE = 0ULL;
 enum DevErr : uint32_t { DE_OVERFLOW = 1, DE_DIV_ZERO = 2 };
 
 // Specialised predicate shapes that bypass the interpreter loop (host sets `fast_kind` after lowering)
@@ -111,7 +114,7 @@ struct FilterParams {
   u64* status;       // per tile: flag(2) | value(62); zeroed before launch
   uint32_t* ticket;       // zeroed before launch
   u64* total;        // out: number of selected rows
-  u64* err;          // ERR_NONE before launch
+  u64* err;          // ERR_NONE (0) before launch
   u64* sel_mask;     // optional: selection bitmap (one u64 per 64 rows), for follow-up kernels
   u64* grp_base;     // optional: output row index of each 64-row group's first selected row
   int16_t n_out;
@@ -140,6 +143,13 @@ struct BitCompactParams {   // bool values / validity bitmaps
   const void* in_bits; int64_t in_bit_offset;
   uint32_t* out_bits;       // zero-initialised; bit k = k-th selected row
   u64* zero_count;     // optional: counts selected rows whose bit is 0 (null count)
+};
+
+struct GatherParams {      // gather_i32_kernel: dst[i] = *src[i]  (batches tiny device->host read-backs into one copy)
+  const int32_t* src[16];
+  int32_t* dst;
+  int32_t n;
+  int32_t pad;
 };
 
 struct Utf8Params {

@@ -361,23 +361,28 @@ namespace {
 constexpr int64_t kTileRows[3] = {1024 * 16, 256 * 8, 256 * 8};
 constexpr int kGridPerCu[3] = {1, 4, 4};
 
-struct Scratch {   // layout of ctx.small (device) and ctx.pinned (host mirror)
-  uint32_t ticket; uint32_t pad0;
+struct Scratch {   // header of ctx.small (device) and layout of ctx.pinned (host mirror)
+  uint32_t ticket; uint32_t pad0;      // --- [0, kPerPass): re-cleared before every pass of a multi-pass filter
   unsigned long long total;
-  unsigned long long err;
-  unsigned long long total_bytes;
   uint32_t ticket2; uint32_t pad1;
+  unsigned long long err;             // --- from here on: cleared once per call (errors accumulate over the passes)
+  unsigned long long total_bytes;
   unsigned long long counters[24];
-  int32_t utf8_ends[16];   // host mirror only: first / last input offset of each Utf8 column (output byte capacity)
+  int32_t utf8_ends[16];              // first / last input offset of each Utf8 column (output byte capacity)
 };
+constexpr size_t kPerPass = 24;
+constexpr size_t kHeader = 512;       // status words start here
+static_assert(sizeof(Scratch) <= kHeader, "scratch header");
 
 void ensure_scratch(Context& ctx, int64_t ntiles) {
-  const size_t need = (size_t)(ntiles + 64) * 8;
-  if (!ctx.status || ctx.status->bytes < need) ctx.status = make_device_buffer(need, ctx.device);
-  if (!ctx.small) ctx.small = make_device_buffer(sizeof(Scratch), ctx.device);
+  if (!ctx.small || ctx.small_tiles < (size_t)ntiles + 64) {
+    ctx.small_tiles = (size_t)ntiles + 64 + (size_t)ntiles / 4;
+    ctx.small = make_device_buffer(kHeader + ctx.small_tiles * 8, ctx.device);
+  }
   if (!ctx.pinned) { check_hip(hipHostMalloc(&ctx.pinned, sizeof(Scratch), hipHostMallocDefault), "hipHostMalloc"); ctx.pinned_bytes = sizeof(Scratch); }
 }
 Scratch* dev_scratch(Context& ctx) { return (Scratch*)ctx.small->ptr; }
+u64* dev_status(Context& ctx) { return (u64*)((uint8_t*)ctx.small->ptr + kHeader); }
 
 void fill_refs(ProgramBlock& pb, const Lowered& lw, const Batch& rec, const std::vector<BufferPtr>& str_bufs) {
   pb.n_instr = (int32_t)lw.prog.size();
@@ -418,7 +423,8 @@ std::vector<BufferPtr> upload_strings(Context& ctx, const Lowered& lw) {
   return out;
 }
 
-[[noreturn]] void throw_device_error(unsigned long long err) {
+[[noreturn]] void throw_device_error(unsigned long long stored) {
+  const unsigned long long err = ~stored;   // the device keeps the complement (see ERR_NONE)
   const int code = (int)(err & 0xff);
   const long long row = (long long)((err >> 8) & ((1ULL << 48) - 1));
   if (code == DE_DIV_ZERO) throw ChqError{CHQ_ERR_ARROW_DIVIDE_BY_ZERO, "Divide by zero error (row " + std::to_string(row) + ")"};
@@ -540,7 +546,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   do {
     FilterParams p{};
     p.nrows = mask_len;
-    p.status = (u64*)ctx.status->ptr;
+    p.status = dev_status(ctx);
     p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
     p.sel_mask = (first && need_followup) ? (u64*)sel_mask->ptr : nullptr;
     p.grp_base = (first && need_followup) ? (u64*)grp_base->ptr : nullptr;
@@ -570,10 +576,11 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     }
     p.n_out = (int16_t)n;
     p.debug = (int32_t)ctx.opt_debug;
-    check_hip(hipMemsetAsync(ctx.status->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset status");
-    check_hip(hipMemsetAsync(ds, 0, 16, ctx.stream), "memset scratch");
-    check_hip(hipMemsetAsync(&ds->ticket2, 0, 8, ctx.stream), "memset scratch");
-    if (first) check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
+    if (first) check_hip(hipMemsetAsync(ds, 0, kHeader + (size_t)(ntiles + 1) * 8, ctx.stream), "memset scratch + status");
+    else {
+      check_hip(hipMemsetAsync(ds, 0, kPerPass, ctx.stream), "memset scratch");
+      check_hip(hipMemsetAsync(dev_status(ctx), 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset status");
+    }
     const int kind = first ? tile_kind : (tile_kind == 2 ? 1 : tile_kind);   // kinds 1 and 2 share a tile size
     if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev0, ctx.stream), "hipEventRecord");
     // Large batches: all complete tiles run in the instantiation that contains no partial-tile code at all; the
@@ -597,13 +604,17 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   } while (next_fixed < fixed_cols.size());
 
   Scratch* hs = (Scratch*)ctx.pinned;
-  check_hip(hipMemcpyAsync(hs, ds, 32, hipMemcpyDeviceToHost, ctx.stream), "read back");
   if (utf8_cols.size() > 8) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 8 Utf8 columns in one batch"};
-  for (size_t k = 0; k < utf8_cols.size(); ++k) {   // input byte span of every Utf8 column = capacity of its output
-    const int32_t* offs = (const int32_t*)rec.cols[utf8_cols[k]].values0();
-    check_hip(hipMemcpyAsync(&hs->utf8_ends[2 * k], offs, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
-    check_hip(hipMemcpyAsync(&hs->utf8_ends[2 * k + 1], offs + mask_len, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
+  if (!utf8_cols.empty()) {   // input byte span of every Utf8 column (= capacity of its output) rides on the same read-back
+    GatherParams gp{};
+    for (size_t k = 0; k < utf8_cols.size(); ++k) {
+      const int32_t* offs = (const int32_t*)rec.cols[utf8_cols[k]].values0();
+      gp.src[2 * k] = offs; gp.src[2 * k + 1] = offs + mask_len;
+    }
+    gp.n = (int32_t)(2 * utf8_cols.size()); gp.dst = ds->utf8_ends;
+    check_hip(launch_gather_i32(gp, ctx.stream), "launch gather_i32_kernel");
   }
+  check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
   if (hs->err != ERR_NONE) throw_device_error(hs->err);
@@ -616,7 +627,6 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     const int fgrid = (int)std::min<int64_t>((ngroups + 31) / 32, (int64_t)ctx.num_cus * 8);
     // ---- Boolean value bitmaps and validity bitmaps -------------------------------------------------
     const size_t words = (size_t)(total + 31) / 32 + 2;
-    check_hip(hipMemsetAsync(&ds->counters[0], 0, sizeof(ds->counters), ctx.stream), "memset counters");
     if (nullable_cols.size() > 24) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 24 nullable columns in one batch"};
     auto bit_compact = [&](const uint8_t* in_bits, int64_t bit_off, u64* zero_counter) {
       auto ob = make_device_buffer(words * 4 + 8, ctx.device);
@@ -671,7 +681,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       o.values = (const uint8_t*)offb->ptr; o.owned.push_back(offb); o.length = total;
       o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
     }
-    check_hip(hipMemcpyAsync(hs, ds, 40 + sizeof(ds->counters), hipMemcpyDeviceToHost, ctx.stream), "read back");
+    check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
     for (size_t k = 0; k < nullable_cols.size(); ++k) {
       Column& o = out.cols[nullable_cols[k]];
@@ -791,7 +801,6 @@ std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::ve
       p.outs[i] = po;
     }
     check_hip(hipMemsetAsync(ds, 0, sizeof(Scratch), ctx.stream), "memset scratch");
-    check_hip(hipMemsetAsync(&ds->err, 0xFF, 8, ctx.stream), "memset err");
     const int tile_kind = pick_tile_kind(ctx, lw, nrows);
     const int64_t ntiles = (nrows + kTileRows[tile_kind] - 1) / kTileRows[tile_kind];
     const int64_t gcap = tile_kind == 0 ? (int64_t)ctx.num_cus * 2 : (int64_t)ctx.num_cus * 8;

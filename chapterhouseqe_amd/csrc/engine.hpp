@@ -19,6 +19,7 @@ hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
+hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
 
@@ -100,7 +101,8 @@ struct Context {
   int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // reusable device scratch
-  BufferPtr status, byte_status, small;   // small: ticket(4) pad total(8) err(8) total_bytes(8) counters...
+  BufferPtr small;          // [Scratch header (512 B)] [status words of the chained scan]: cleared by ONE memset per call
+  size_t small_tiles = 0;   // status words the block has room for
   void* pinned = nullptr;                  // pinned host staging for small read-backs (256 B)
   size_t pinned_bytes = 0;
 

@@ -110,7 +110,7 @@ __device__ __forceinline__ int32_t f32_key(uint32_t b) { int32_t s = (int32_t)b;
 __device__ __forceinline__ int64_t f64_key(uint64_t b) { int64_t s = (int64_t)b; return s ^ (int64_t)(((uint64_t)(s >> 63)) >> 1); }
 
 __device__ __forceinline__ void report_error(u64* err, uint32_t ref_order, int64_t row, uint32_t code) {
-  atomicMin(err, ((u64)ref_order << 56) | ((u64)row << 8) | (u64)code);
+  atomicMax(err, ~(((u64)ref_order << 56) | ((u64)row << 8) | (u64)code));
 }
 
 // value classes the interpreter computes in
@@ -1194,6 +1194,14 @@ hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, i
 }
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL((bit_compact_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+__global__ void gather_i32_kernel(const GatherParams p) {
+  const int i = threadIdx.x;
+  if (i < p.n) p.dst[i] = *p.src[i];
+}
+hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_i32_kernel, dim3(1), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream) {   // 8192-row tiles
