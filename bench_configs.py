@@ -148,7 +148,69 @@ def main():
         ctx.set_option("trim_pool", 1)
         torch.cuda.empty_cache()
 
+    def run_group_case(name, n, rows_per_batch, spec, where, seed=1, note=""):
+        """the same rows cut into reference-sized batches (physical_planner.rs:323) and filtered by ONE
+        chq_filter_records call; compared with calling chq_filter_record per batch on a subset"""
+        if args.only and args.only not in name:
+            return
+        n = max(4 * rows_per_batch, int(n * args.scale)) // rows_per_batch * rows_per_batch
+        nb = n // rows_per_batch
+        keep, cols = gen(n, spec, seed)
+        al = [[] for _ in cols]
+        pred = parse_expr(where)
+        widths = [4 for _ in cols]
+        t0 = time.perf_counter()
+        devs = [chq.DeviceRecordBatch.from_device_pointers(
+            [(c[0], c[1], c[2] + w * b * rows_per_batch) for c, w in zip(cols, widths)], rows_per_batch, ctx=ctx) for b in range(nb)]
+        grp = chq.RecordGroup(devs, ctx)
+        wrap_s = time.perf_counter() - t0
+        # parity: first batches against the oracle, every batch's row count against torch
+        m = min(nb, 8)
+        got = chq.filter_records(devs[:m], al, pred, ctx=ctx)
+        host = host_prefix(keep, spec, m * rows_per_batch)
+        for b in range(m):
+            exp = O.filter_record(host.slice(b * rows_per_batch, rows_per_batch), al, pred)
+            if not batches_identical(got[b].to_host(), exp):
+                raise SystemExit(f"{name}: batch {b} differs from the oracle")
+        del got
+        counts = chq.filter_records(grp, al, pred, ctx=ctx, wrap=False)
+        rows_out = sum(counts)
+        fk, wall = [], []
+        for it in range(args.steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            counts = chq.filter_records(grp, al, pred, ctx=ctx, wrap=False)
+            t1 = time.perf_counter()
+            st = ctx.last_stats()
+            if it:
+                fk.append(st["kernel_ns"] / 1e6); wall.append((t1 - t0) * 1e3)
+        fk.sort(); wall.sort()
+        # the per-batch loop on a subset, same batches
+        sub = min(nb, 2000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for b in range(sub):
+            chq.filter_record(devs[b], al, pred, ctx=ctx).release()
+        loop_s = time.perf_counter() - t0
+        alg = st["bytes_read_alg"] + st["bytes_written_alg"]
+        r = {"case": name, "rows": n, "batches": nb, "rows_per_batch": rows_per_batch, "rows_out": rows_out, "selectivity": rows_out / n,
+             "where": where, "group_kernel_ms": fk[len(fk) // 2], "group_call_wall_ms": wall[len(wall) // 2], "launches": st["launches"],
+             "tiles": st["tiles"], "alg_bytes": alg, "group_kernel_GBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9,
+             "group_kernel_frac_of_8TBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9 / HBM_PEAK,
+             "rows_per_s_group_call": n / (wall[len(wall) // 2] * 1e-3),
+             "per_batch_loop_us_per_batch": loop_s / sub * 1e6, "rows_per_s_per_batch_loop": sub * rows_per_batch / loop_s,
+             "wrap_inputs_s": wrap_s, "note": note}
+        results.append(r)
+        print(json.dumps(r), flush=True)
+        grp.release()
+        del devs, keep
+        ctx.set_option("trim_pool", 1)
+        torch.cuda.empty_cache()
+
     f3 = [("value0", "f32", 0, 100), ("value1", "f32", 0, 100), ("value2", "f32", 0, 100)]
+    run_group_case("group2 value2>10, 10k-row batches", 1_000_000_000, 10_000, f3, "value2 > 10.0", seed=0xC0FFEE,
+                   note="call wall time includes building the tile table, exporting and releasing every output batch through ctypes")
+    run_group_case("group2 value2>10, 100k-row batches", 1_000_000_000, 100_000, f3, "value2 > 10.0", seed=0xC0FFEE)
     run_case("config2 value2>10 (s~0.9)", 1_000_000_000, f3, "value2 > 10.0", seed=0xC0FFEE)
     run_case("config2b value2>90 (s~0.1)", 1_000_000_000, f3, "value2 > 90.0", seed=0xC0FFEE)
     run_case("config2c value2>50 (s~0.5)", 1_000_000_000, f3, "value2 > 50.0", seed=0xC0FFEE)

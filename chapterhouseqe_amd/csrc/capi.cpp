@@ -170,6 +170,36 @@ chq_status chq_filter_record(chq_ctx* ctx, const ArrowDeviceArray* rec, const Ar
   });
 }
 
+chq_status chq_filter_records(chq_ctx* ctx, int n_records, const ArrowDeviceArray* const* recs, const ArrowSchema* schema,
+                              const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
+                              ArrowDeviceArray* outs, ArrowSchema* out_schemas) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  for (int i = 0; i < n_records; ++i) mark_released(outs ? &outs[i] : nullptr, out_schemas ? &out_schemas[i] : nullptr);
+  return guarded(ctx, [&] {
+    require(expr, "expression");
+    if (n_records < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "negative record count"};
+    if (n_records == 0) return;
+    require(recs, "record array"); require(outs, "output arrays"); require(out_schemas, "output schemas");
+    if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    std::vector<Batch> in;
+    in.reserve((size_t)n_records);
+    for (int i = 0; i < n_records; ++i) { require(recs[i], "record"); in.push_back(import_batch(recs[i], schema)); }
+    std::vector<Batch> res = filter_records(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM);
+    int done = 0;
+    try {
+      for (; done < n_records; ++done) export_batch(std::move(res[(size_t)done]), out_device, &outs[done], &out_schemas[done]);
+    } catch (...) {   // no partial output
+      for (int i = 0; i < done; ++i) {
+        if (outs[i].array.release) outs[i].array.release(&outs[i].array);
+        if (out_schemas[i].release) out_schemas[i].release(&out_schemas[i]);
+      }
+      throw;
+    }
+  });
+}
+
 chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n_fields, const ArrowDeviceArray* rec,
                               const ArrowSchema* schema, const chq_table_aliases* table_aliases, int out_device,
                               ArrowDeviceArray* out, ArrowSchema* out_schema) {

@@ -121,8 +121,21 @@ struct FilterParams {
   int16_t stash_ref;      // program column-ref whose raw tile values stay in LDS between P and C (-1: none); when set,
                           // that column is outs[n_out - 1] and is copied from LDS instead of being fetched again
   int32_t debug;          // experiments only: bit0 = no inter-tile dependency (base = tile * TILE), bit1 = skip last column
+  // Batch-group launch (chq_filter_records): many batches of one schema, one launch, one dense compaction.  Tiles never
+  // straddle batches; row `tile` of this table (group_stride words) = { first row of the tile inside its batch, rows of
+  // that batch, value pointers of the n_refs program inputs, input pointers of the n_out copied columns }.
+  // nullptr = single batch (pointers come from pb.refs / outs, rows are tile * TILE).  PARTIAL instantiation only.
+  const u64* group;
+  int64_t group_stride;
   ProgramBlock pb;
   OutCol outs[MAX_OUT];
+};
+
+struct GatherStatusParams {   // dst[i] = value part of status[idx[i]]
+  const u64* status;
+  const int64_t* idx;
+  u64* dst;
+  int64_t n;
 };
 
 struct ProjectParams {

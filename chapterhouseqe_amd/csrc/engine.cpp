@@ -87,6 +87,7 @@ Context::~Context() {
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
   if (pinned) (void)hipHostFree(pinned);
+  if (pinned_tbl) (void)hipHostFree(pinned_tbl);
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -691,6 +692,225 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   }
   for (Column& o : out.cols) o.length = total;
   return out;
+}
+
+// =================================================================================================
+// filter_records: filter_record over a group of batches that share one schema, in ONE launch.
+//
+// The reference hands the filter operator one 10 000-row batch at a time (physical_planner.rs:323); at that size a
+// call is bounded by launch + read-back latency, not by HBM.  A group call keeps the per-batch semantics (one output
+// batch per input batch, same rows, same order) but runs one chained-scan compaction over all tiles of all batches:
+// tiles never straddle batches, a per-tile table carries the batch-local row range and the column pointers, the output
+// of every column is one dense buffer and batch b's output is the slice between the inclusive prefixes of the last
+// tiles of batches b-1 and b.
+//
+// Fast path: every column fixed-width (not Boolean / Utf8) and free of nulls, every batch >= 2 rows, predicate not
+// literal-only, no static error.  Anything else -- and any data-dependent error -- takes the per-batch loop, which
+// reports exactly what chq_filter_record would for the earliest failing batch.
+// =================================================================================================
+namespace {
+void add_stats(chq_call_stats& acc, const chq_call_stats& s) {
+  acc.rows_in += s.rows_in; acc.rows_out += s.rows_out; acc.tiles += s.tiles; acc.launches += s.launches;
+  acc.bytes_read_alg += s.bytes_read_alg; acc.bytes_written_alg += s.bytes_written_alg; acc.kernel_ns += s.kernel_ns;
+}
+void ensure_pinned_table(Context& ctx, size_t bytes) {
+  if (ctx.pinned_tbl_bytes >= bytes) return;
+  if (ctx.pinned_tbl) (void)hipHostFree(ctx.pinned_tbl);
+  ctx.pinned_tbl = nullptr; ctx.pinned_tbl_bytes = 0;
+  const size_t cap = bytes + bytes / 4 + 4096;
+  check_hip(hipHostMalloc(&ctx.pinned_tbl, cap, hipHostMallocDefault), "hipHostMalloc (group table)");
+  ctx.pinned_tbl_bytes = cap;
+}
+}  // namespace
+
+std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
+                                  const Expr& expr, bool out_on_device) {
+  const size_t nb = recs.size();
+  auto per_batch_loop = [&]() {
+    std::vector<Batch> outs;
+    chq_call_stats acc{};
+    for (const Batch& r : recs) {
+      Batch dev = to_device(ctx, r);
+      Batch o = filter_record(ctx, dev, plan_columns(dev, aliases), expr);
+      add_stats(acc, ctx.stats);
+      outs.push_back(out_on_device ? std::move(o) : to_host(ctx, o));
+    }
+    ctx.stats = acc;
+    return outs;
+  };
+  if (nb < 2) return per_batch_loop();
+
+  // ---- eligibility -----------------------------------------------------------------------------------
+  const size_t ncols = recs[0].cols.size();
+  if (ncols == 0 || (int)ncols > MAX_OUT) return per_batch_loop();
+  int64_t total_rows = 0, max_rows = 0;
+  const bool host_in = !recs[0].on_device;
+  for (const Batch& r : recs) {
+    if (r.cols.size() != ncols || r.nrows < 2 || r.on_device == host_in) return per_batch_loop();
+    for (size_t i = 0; i < ncols; ++i) {
+      const Column& c = r.cols[i];
+      if (c.type == T_BOOL || c.type == T_UTF8 || c.type != recs[0].cols[i].type || c.width != recs[0].cols[i].width) return per_batch_loop();
+      if (c.validity && c.null_count != 0) {
+        if (r.on_device || c.null_count > 0) return per_batch_loop();
+        if (count_nulls_host(c.validity, c.offset, c.length) != 0) return per_batch_loop();
+      }
+    }
+    total_rows += r.nrows; max_rows = std::max(max_rows, r.nrows);
+  }
+  const std::vector<PlanColumn> pcols = plan_columns(recs[0], aliases);
+  TypedExpr te = type_expr(expr, pcols, recs[0].nrows, ctx.opt_enable_minus);
+  if (te.pending_code) return per_batch_loop();
+  const Node& root = te.at(te.root);
+  if (root.type != T_BOOL || root.len1) return per_batch_loop();
+  Lowered lw;
+  lower_expr(te, te.root, pcols, lw);
+  if (!lw.strs.empty()) return per_batch_loop();
+
+  ctx.stats = chq_call_stats{};
+  ctx.stats.rows_in = total_rows;
+
+  // ---- inputs: device pointers per batch and column ------------------------------------------------------
+  // host batches are packed column-wise into one staging block per column and uploaded with one copy each
+  std::vector<BufferPtr> staged;
+  std::vector<std::vector<const uint8_t*>> in_ptr(nb, std::vector<const uint8_t*>(ncols));
+  if (host_in) {
+    std::vector<uint8_t> pack;
+    for (size_t i = 0; i < ncols; ++i) {
+      const int64_t w = recs[0].cols[i].width;
+      pack.resize((size_t)(total_rows * w));
+      auto db = make_device_buffer((size_t)(total_rows * w) + 16, ctx.device);
+      int64_t at = 0;
+      for (size_t b = 0; b < nb; ++b) {
+        memcpy(pack.data() + at, recs[b].cols[i].values0(), (size_t)(recs[b].nrows * w));
+        in_ptr[b][i] = (const uint8_t*)db->ptr + at;
+        at += recs[b].nrows * w;
+      }
+      check_hip(hipMemcpy(db->ptr, pack.data(), (size_t)at, hipMemcpyHostToDevice), "upload packed column");
+      staged.push_back(db);
+    }
+  } else {
+    for (size_t b = 0; b < nb; ++b)
+      for (size_t i = 0; i < ncols; ++i) in_ptr[b][i] = (const uint8_t*)recs[b].cols[i].values0();
+  }
+
+  // ---- tiling ------------------------------------------------------------------------------------------------
+  int tile_kind;
+  if (lw.wide || lw.num_temps > 0) tile_kind = 2;
+  else if (ctx.opt_tile_kind >= 0) tile_kind = (int)ctx.opt_tile_kind;
+  else tile_kind = (total_rows / (int64_t)nb) >= 6144 ? 0 : 1;
+  const int64_t tile_rows = kTileRows[tile_kind];
+  int64_t ntiles = 0;
+  for (const Batch& r : recs) ntiles += (r.nrows + tile_rows - 1) / tile_rows;
+  ensure_scratch(ctx, ntiles);
+  Scratch* ds = dev_scratch(ctx);
+
+  // column order of the launch: the stashed predicate column goes last (see filter_record)
+  std::vector<int> launch_cols;
+  for (size_t i = 0; i < ncols; ++i) launch_cols.push_back((int)i);
+  FilterParams p{};
+  p.stash_ref = -1;
+  if (ctx.opt_stash) {
+    for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
+      const Column& c = recs[0].cols[lw.refs[r]];
+      if (c.width > 4) continue;
+      auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
+      if (it != launch_cols.end()) { launch_cols.erase(it); launch_cols.push_back(lw.refs[r]); p.stash_ref = (int16_t)r; }
+    }
+  }
+  const size_t nrefs = lw.refs.size(), nout = launch_cols.size();
+  const size_t stride = 2 + nrefs + nout;
+
+  // ---- tile table + index of every batch's last tile: built in pinned memory, one upload ---------------------
+  const size_t tbl_words = (size_t)ntiles * stride;
+  const size_t bytes_tbl = tbl_words * 8, bytes_idx = nb * 8, bytes_cnt = nb * 8;
+  ensure_pinned_table(ctx, bytes_tbl + bytes_idx + bytes_cnt);
+  u64* h_tbl = (u64*)ctx.pinned_tbl;
+  int64_t* h_idx = (int64_t*)(h_tbl + tbl_words);
+  u64* h_cnt = (u64*)(h_idx + nb);
+  {
+    u64* w = h_tbl;
+    int64_t tile = 0;
+    for (size_t b = 0; b < nb; ++b) {
+      const int64_t rows = recs[b].nrows;
+      for (int64_t r0 = 0; r0 < rows; r0 += tile_rows, ++tile) {
+        *w++ = (u64)r0; *w++ = (u64)rows;
+        for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
+        for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
+      }
+      h_idx[b] = tile - 1;   // rows >= 2: every batch owns at least one tile
+    }
+  }
+  auto d_tbl = make_device_buffer(bytes_tbl + bytes_idx + bytes_cnt + 16, ctx.device);
+  check_hip(hipMemcpyAsync(d_tbl->ptr, h_tbl, bytes_tbl + bytes_idx, hipMemcpyHostToDevice, ctx.stream), "upload tile table");
+
+  // ---- dense outputs ---------------------------------------------------------------------------------------
+  std::vector<BufferPtr> dense(ncols);
+  for (size_t i = 0; i < ncols; ++i) {
+    dense[i] = make_device_buffer((size_t)(total_rows * recs[0].cols[i].width) + 16, ctx.device);
+    ctx.stats.bytes_read_alg += total_rows * recs[0].cols[i].width;
+  }
+  p.nrows = ntiles * tile_rows;   // only locates the last tile; per-tile row ranges come from the table
+  p.status = dev_status(ctx);
+  p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
+  fill_refs(p.pb, lw, recs[0], {});
+  p.pb.fast_kind = FAST_NONE;
+  for (size_t k = 0; k < nout; ++k) {
+    p.outs[k].in = nullptr; p.outs[k].out = dense[launch_cols[k]]->ptr; p.outs[k].width = (uint32_t)recs[0].cols[launch_cols[k]].width;
+  }
+  p.n_out = (int16_t)nout;
+  p.debug = (int32_t)(ctx.opt_debug & ~1);
+  p.group = (const u64*)d_tbl->ptr; p.group_stride = (int64_t)stride;
+  p.tile_begin = 0; p.tile_end = ntiles;
+  check_hip(hipMemsetAsync(ds, 0, kHeader + (size_t)(ntiles + 1) * 8, ctx.stream), "memset scratch + status");
+  const int grid_cap = ctx.num_cus * (ctx.opt_grid_per_cu > 0 ? (int)ctx.opt_grid_per_cu : kGridPerCu[tile_kind]);
+  if (ctx.opt_time_kernels && !ctx.ev0) { check_hip(hipEventCreate(&ctx.ev0), "hipEventCreate"); check_hip(hipEventCreate(&ctx.ev1), "hipEventCreate"); }
+  if (ctx.opt_time_kernels) check_hip(hipEventRecord(ctx.ev0, ctx.stream), "hipEventRecord");
+  check_hip(launch_filter(p, tile_kind, true, (int)std::min<int64_t>(ntiles, grid_cap), ctx.stream), "launch filter_fused_kernel (group)");
+  if (ctx.opt_time_kernels) check_hip(hipEventRecord(ctx.ev1, ctx.stream), "hipEventRecord");
+  GatherStatusParams gp{};
+  gp.status = dev_status(ctx); gp.idx = (const int64_t*)((const uint8_t*)d_tbl->ptr + bytes_tbl);
+  gp.dst = (u64*)((uint8_t*)d_tbl->ptr + bytes_tbl + bytes_idx); gp.n = (int64_t)nb;
+  check_hip(launch_gather_status(gp, ctx.stream), "launch gather_status_kernel");
+  ctx.stats.launches = 2; ctx.stats.tiles = ntiles;
+  Scratch* hs = (Scratch*)ctx.pinned;
+  check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
+  check_hip(hipMemcpyAsync(h_cnt, gp.dst, bytes_cnt, hipMemcpyDeviceToHost, ctx.stream), "read back batch prefixes");
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
+  if (hs->err != ERR_NONE) return per_batch_loop();   // reports the earliest failing batch, as the reference's loop would
+  const int64_t total = (int64_t)hs->total;
+  ctx.stats.rows_out = total;
+  for (size_t i = 0; i < ncols; ++i) ctx.stats.bytes_written_alg += total * recs[0].cols[i].width;
+
+  // ---- slice the dense outputs ---------------------------------------------------------------------------------
+  std::vector<BufferPtr> host_dense;
+  if (!out_on_device) {
+    for (size_t i = 0; i < ncols; ++i) {
+      const size_t bytes = (size_t)(total * recs[0].cols[i].width);
+      auto hb = make_host_buffer(bytes + 16);
+      if (bytes) check_hip(hipMemcpyAsync(hb->ptr, dense[i]->ptr, bytes, hipMemcpyDeviceToHost, ctx.stream), "download dense column");
+      host_dense.push_back(hb);
+    }
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  }
+  std::vector<Batch> outs(nb);
+  int64_t begin = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    const int64_t end = (int64_t)h_cnt[b];
+    Batch& o = outs[b];
+    o.on_device = out_on_device; o.device_id = out_on_device ? ctx.device : -1;
+    o.nrows = end - begin;
+    for (size_t i = 0; i < ncols; ++i) {
+      Column c = empty_like(recs[b].cols[i]);
+      const BufferPtr& buf = out_on_device ? dense[i] : host_dense[i];
+      c.values = (const uint8_t*)buf->ptr + begin * c.width;
+      c.length = o.nrows;
+      c.owned.push_back(buf);
+      o.cols.push_back(std::move(c));
+    }
+    begin = end;
+  }
+  return outs;
 }
 
 // =================================================================================================

@@ -20,6 +20,7 @@ hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, i
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
+hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
 
@@ -105,6 +106,8 @@ struct Context {
   size_t small_tiles = 0;   // status words the block has room for
   void* pinned = nullptr;                  // pinned host staging for small read-backs (256 B)
   size_t pinned_bytes = 0;
+  void* pinned_tbl = nullptr;              // pinned staging of a batch-group launch (tile table, per-batch prefixes)
+  size_t pinned_tbl_bytes = 0;
 
   ~Context();
 };
@@ -121,6 +124,9 @@ Batch to_host(Context& ctx, const Batch& b);
 
 // the record-level operations (throw ChqError)
 Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr);
+// one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says
+std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
+                                  const Expr& expr, bool out_on_device);
 Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_dev,
                      const std::vector<PlanColumn>& pcols);
 Column compute_value(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr,

@@ -158,6 +158,7 @@ struct Interp {
   int lane, wv;
   uint32_t* stash = nullptr;   // LDS [R][BLOCK]: raw values of column-ref `stash_ref`, reused by the copy phase
   int stash_ref = -1;
+  const u64* ptr_row = nullptr;   // batch-group launch: value pointer of column-ref k is ptr_row[k] (PARTIAL only)
 
   __device__ __forceinline__ void set_rows(int64_t tile_start, int64_t nrows_, int lane_, int wv_) {
     lane = lane_; wv = wv_; nrows = nrows_;
@@ -193,7 +194,8 @@ struct Interp {
 
   // ---- operand fetch ---------------------------------------------------------------------------
   template <bool FULL>
-  __device__ __forceinline__ void fetch_values(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH]) {
+  __device__ __forceinline__ void fetch_values(const ColRef& cr, const void* values, uint32_t (&l)[R], uint32_t (&h)[RH]) {
+    struct { int type; const void* values; } c{cr.type, values};
     // FULL: the wave's 64*R rows are all inside the batch -> element j*64+lane, no clamping (immediate offsets)
 #define IDX(j) (FULL ? (j) * 64 + lane : off(j))
     switch (c.type) {
@@ -222,19 +224,20 @@ struct Interp {
 #undef IDX
   }
 
-  __device__ __forceinline__ void fetch_col(const ColRef& c, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
+  __device__ __forceinline__ void fetch_col(const ColRef& c, int ref_idx, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
     b = 0;
     if constexpr (!PARTIAL) {
       if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
-      else fetch_values<true>(c, l, h);
+      else fetch_values<true>(c, c.values, l, h);
     } else {
+      const void* vals = ptr_row ? (const void*)ptr_row[ref_idx] : c.values;
 #pragma unroll
       for (int j = 0; j < R; ++j) l[j] = 0;
 #pragma unroll
       for (int j = 0; j < RH; ++j) h[j] = 0;
       if (nact > 0) {
-        if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
-        else fetch_values<false>(c, l, h);
+        if (c.type == T_BOOL) b = fetch_flags(vals, c.bool_bit_offset);
+        else fetch_values<false>(c, vals, l, h);
       }
     }
     v = c.validity ? (fetch_flags(c.validity, c.validity_bit_offset) & actv) : actv;
@@ -516,7 +519,7 @@ struct Interp {
       const bool bconst = in.src_kind == SRC_CONST;
       const uint32_t cl = (uint32_t)in.imm, ch = (uint32_t)(in.imm >> 32);
       if (in.op == OP_LOAD && in.src_kind == SRC_COL) {   // straight into the accumulator
-        fetch_col(pb.refs[in.src_idx], lo, hi, bitsv, validv);
+        fetch_col(pb.refs[in.src_idx], in.src_idx, lo, hi, bitsv, validv);
         if (stash && (int)in.src_idx == stash_ref) {
 #pragma unroll
           for (int j = 0; j < R; ++j) stash[j * BLOCK + tix] = lo[j];
@@ -526,7 +529,7 @@ struct Interp {
         continue;
       }
       if (in.src_kind == SRC_COL) {
-        fetch_col(pb.refs[in.src_idx], bl, bh, bb, bv);
+        fetch_col(pb.refs[in.src_idx], in.src_idx, bl, bh, bb, bv);
         if (stash && (int)in.src_idx == stash_ref) {
 #pragma unroll
           for (int j = 0; j < R; ++j) stash[j * BLOCK + tix] = bl[j];
@@ -655,7 +658,15 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     const int64_t tile = uniform64(s_tile[buf]);
     if (tile >= ntiles) return;
     Interp<BLOCK, R, WIDE, PARTIAL> it;
-    it.set_rows(tile * TILE, p.nrows, lane, wv);
+    int64_t row0 = tile * TILE, nr = p.nrows;
+    if constexpr (PARTIAL) {
+      if (p.group) {   // batch-group launch: the tile's rows and column pointers come from the tile table
+        const u64* trow = p.group + tile * p.group_stride;
+        row0 = uniform64((int64_t)trow[0]); nr = uniform64((int64_t)trow[1]);
+        it.ptr_row = trow + 2;
+      }
+    }
+    it.set_rows(row0, nr, lane, wv);
     if (p.stash_ref >= 0) { it.stash = s_stash[buf]; it.stash_ref = p.stash_ref; }
     if (!PARTIAL && p.pb.fast_kind == FAST_CMP_CONST) it.run_cmp_const(p.pb);
     else it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE, PARTIAL>&) {});
@@ -698,10 +709,23 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     u64 off0 = s_base;
     for (int w = 0; w < wv; ++w) off0 += s_wave_cnt[buf][w];
     off0 = (u64)uniform64((int64_t)off0);
-    const int64_t w0 = tile * TILE + (int64_t)wv * 64 * R;
+    int64_t row0 = tile * TILE, nr = p.nrows;
+    const u64* in_row = nullptr;   // batch-group launch: input pointers of the copied columns
+    if constexpr (PARTIAL) {
+      if (p.group) {
+        const u64* trow = p.group + tile * p.group_stride;
+        row0 = uniform64((int64_t)trow[0]); nr = uniform64((int64_t)trow[1]);
+        in_row = trow + 2 + p.pb.n_refs;
+      }
+    }
+    auto in_ptr = [&](int k) -> const void* {
+      if constexpr (PARTIAL) { if (in_row) return (const void*)in_row[k]; }
+      return p.outs[k].in;
+    };
+    const int64_t w0 = row0 + (int64_t)wv * 64 * R;
     int nact = 64 * R;
     if constexpr (PARTIAL) {
-      const int64_t rem = p.nrows - w0;
+      const int64_t rem = nr - w0;
       nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
       if (nact <= 0) return;
     }
@@ -724,7 +748,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         // stored at off0 + (selected rows in earlier slots) + rank of the lane among the selected lanes of its slot
 #define LOAD_IDX(j) (FULL ? (j) * 64 + lane : (((j) * 64 + lane) < nact ? ((j) * 64 + lane) : nact - 1))
 #define COPY_COL(TY, CH)                                                                              \
-  { const TY* src = (const TY*)oc.in + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;            \
+  { const TY* src = (const TY*)in_ptr(c) + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;        \
     _Pragma("unroll") for (int j0 = 0; j0 < R; j0 += CH) {                                             \
       TY v[CH];                                                                                        \
       _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) v[jj] = src[LOAD_IDX(j0 + jj)];                \
@@ -743,7 +767,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
             while (cl + 1 < ncopy && p.outs[cl + 1].width == 4) ++cl;
             uint32_t va[R], vb[R];
             auto ld = [&](int k, uint32_t (&v)[R]) {
-              const uint32_t* src = (const uint32_t*)p.outs[k].in + w0;
+              const uint32_t* src = (const uint32_t*)in_ptr(k) + w0;
 #pragma unroll
               for (int j = 0; j < R; ++j) v[j] = src[LOAD_IDX(j)];
             };
@@ -768,7 +792,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           } break;
           case 8: COPY_COL(uint2, (R >= 8 ? 8 : R)) break;
           default: {   // 16-byte values (decimal128 ...): named registers, a private array would be promoted to LDS
-            const uint4* src = (const uint4*)oc.in + w0; uint4* dst = (uint4*)oc.out + off0; unsigned run = 0;
+            const uint4* src = (const uint4*)in_ptr(c) + w0; uint4* dst = (uint4*)oc.out + off0; unsigned run = 0;
 #pragma unroll
             for (int j0 = 0; j0 < R; j0 += 2) {
               const uint4 va = src[LOAD_IDX(j0)], vb = src[LOAD_IDX(j0 + 1)];
@@ -1199,6 +1223,15 @@ hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t s
 __global__ void gather_i32_kernel(const GatherParams p) {
   const int i = threadIdx.x;
   if (i < p.n) p.dst[i] = *p.src[i];
+}
+__global__ void gather_status_kernel(const GatherStatusParams p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < p.n) p.dst[i] = ST_VAL(p.status[p.idx[i]]);
+}
+hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream) {
+  if (p.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_status_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, p);
+  return hipGetLastError();
 }
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(gather_i32_kernel, dim3(1), dim3(64), 0, stream, p);

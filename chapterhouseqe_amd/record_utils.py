@@ -300,6 +300,66 @@ def filter_record(rec: Record, table_aliases: Optional[Sequence[Sequence[str]]],
     return _finish(ctx, rc, out, dev_out)
 
 
+class RecordGroup:
+    """A prepared argument block for `filter_records`: the C pointer array over a list of same-schema batches.
+    Building it once lets a caller that re-filters the same batches (benchmarks) keep Python out of the call."""
+
+    def __init__(self, recs: Sequence[Record], ctx: Optional[Context] = None):
+        if not recs:
+            raise ValueError("empty record group")
+        kinds = {isinstance(r, DeviceRecordBatch) for r in recs}
+        if len(kinds) != 1:
+            raise ValueError("a record group is all host batches or all device batches")
+        self.on_device = kinds.pop()
+        self.ctx = ctx or (recs[0].ctx if self.on_device else default_context())
+        self._cbs = [r._cb if self.on_device else _export_host(r) for r in recs]
+        self._own = not self.on_device
+        self.n = len(recs)
+        self.ptrs = (C.POINTER(L.ArrowDeviceArray) * self.n)(*[C.pointer(cb.array) for cb in self._cbs])
+        self.schema = self._cbs[0].schema
+
+    def release(self):
+        if self._own:
+            for cb in self._cbs:
+                cb.release()
+        self._cbs = []
+
+
+def filter_records(recs, table_aliases: Optional[Sequence[Sequence[str]]], expr: A.Expr, *,
+                   ctx: Optional[Context] = None, device_result: Optional[bool] = None, wrap: bool = True):
+    """`[filter_record(r, table_aliases, expr) for r in recs]` in one call (`chq_filter_records`): the loop of
+    filter_task.rs:78-126 below the boundary.  Same-schema batches; fixed-width null-free groups run in ONE
+    kernel launch.  `recs` is a sequence of batches or a prepared `RecordGroup`.  With `wrap=False` the outputs
+    are released immediately and only the per-batch row counts are returned (benchmarks)."""
+    grp = recs if isinstance(recs, RecordGroup) else RecordGroup(recs, ctx)
+    ctx = ctx or grp.ctx
+    dev_out = grp.on_device if device_result is None else device_result
+    e = _expr_to_c(expr)
+    al = _Aliases(table_aliases)
+    outs = (L.ArrowDeviceArray * grp.n)()
+    schemas = (L.ArrowSchema * grp.n)()
+    try:
+        rc = L.lib().chq_filter_records(ctx.handle, grp.n, grp.ptrs, C.byref(grp.schema), al.ptr, e,
+                                        L.ARROW_DEVICE_ROCM if dev_out else L.ARROW_DEVICE_CPU, outs, schemas)
+    finally:
+        L.lib().chq_expr_free(e)
+        if grp is not recs:
+            grp.release()
+    if rc:
+        raise ChqError(rc, ctx.last_error())
+    results = []
+    for i in range(grp.n):
+        cb = _CBatch()   # struct copy = Arrow "move": the slots of the call arrays are never touched again
+        C.memmove(C.addressof(cb.array), C.addressof(outs[i]), C.sizeof(L.ArrowDeviceArray))
+        C.memmove(C.addressof(cb.schema), C.addressof(schemas[i]), C.sizeof(L.ArrowSchema))
+        if not wrap:
+            results.append(int(cb.array.array.length))
+            cb.release()
+        else:
+            results.append(DeviceRecordBatch(ctx, cb) if dev_out else _import_host(cb))
+    return results
+
+
 def project_record(fields: Sequence[A.SelectItem], record: Record, table_aliases: Optional[Sequence[Sequence[str]]], *,
                    ctx: Optional[Context] = None, device_result: Optional[bool] = None):
     """RU/record_projection.rs:16-76."""

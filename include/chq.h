@@ -150,6 +150,19 @@ chq_status chq_filter_record(chq_ctx* ctx, const struct ArrowDeviceArray* rec, c
                              const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
                              struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
 
+/* chq_filter_record over `n_records` batches of ONE schema, in one call: out[i] is exactly what
+ * chq_filter_record(recs[i]) returns, and on failure the status / message are those of the first
+ * batch (in array order) whose single call fails; nothing is returned then.  This is the loop of
+ * filter_task.rs:78-126 (get_next_record -> filter_record -> send) hoisted below the boundary: the
+ * reference's batches are 10 000 rows (src/planner/physical_planner.rs:323), far too small to fill
+ * the GPU one at a time.  When every column is fixed-width without nulls, all batches run in ONE
+ * kernel launch (one chained compaction; out[i] are slices of one dense buffer per column); other
+ * groups are processed batch by batch inside the call.  `outs` / `out_schemas`: n_records entries. */
+chq_status chq_filter_records(chq_ctx* ctx, int n_records, const struct ArrowDeviceArray* const* recs,
+                              const struct ArrowSchema* schema, const chq_table_aliases* table_aliases,
+                              const chq_expr* expr, int out_device, struct ArrowDeviceArray* outs,
+                              struct ArrowSchema* out_schemas);
+
 /* RU/record_projection.rs:16-76 */
 chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n_fields,
                               const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,

@@ -1,0 +1,218 @@
+"""GPU: chq_filter_records (one launch for a group of same-schema batches) against the CPU oracle and against
+chq_filter_record called batch by batch -- the loop of filter_task.rs:78-126 that the group call replaces.
+Bit-exact: the group call only moves values."""
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import chapterhouseqe_amd as chq
+from chapterhouseqe_amd.sqlparse import parse_expr
+from oracle import oracle as O
+
+from .cases import empty_aliases
+from .test_gpu_scale import _dtod
+from .helpers import batches_identical, explain_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = chq.Context(0)
+    yield c
+    c.close()
+
+
+def fixed_batch(n, seed, with_wide=True):
+    rng = np.random.default_rng(seed)
+    cols = {
+        "id": pa.array(rng.integers(-10**6, 10**6, n).astype(np.int32)),
+        "value1": pa.array((rng.random(n) * 40 - 10).astype(np.float32)),
+        "value2": pa.array((rng.random(n) * 40 - 10).astype(np.float32)),
+        "b": pa.array(rng.integers(-128, 128, n).astype(np.int8)),
+        "h": pa.array(rng.integers(0, 65536, n).astype(np.uint16)),
+    }
+    if with_wide:
+        cols["big"] = pa.array(rng.integers(-10**12, 10**12, n).astype(np.int64))
+        cols["d"] = pa.array(rng.random(n) * 100)
+    return pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys()))
+
+
+def check_group(ctx, recs, sql, device):
+    al = empty_aliases(recs[0])
+    e = parse_expr(sql)
+    exp = [O.filter_record(r, al, e) for r in recs]
+    if device:
+        devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]
+        got = [g.to_host() for g in chq.filter_records(devs, al, e, ctx=ctx)]
+    else:
+        got = chq.filter_records(recs, al, e, ctx=ctx)
+    assert len(got) == len(exp)
+    for i, (g, x) in enumerate(zip(got, exp)):
+        assert batches_identical(g, x), f"{sql}: batch {i} of {len(recs)} (rows {recs[i].num_rows}):\n{explain_diff(g, x)}"
+    return ctx.last_stats()
+
+
+RAGGED = [2, 3, 63, 64, 65, 2047, 2048, 2049, 10_000, 16_383, 16_384, 16_385, 40_000, 5]
+PREDICATES = ["value2 > 10.0", "id % 2 = 0 and value1 < 20.0", "big / 3 > h or d * 2.0 < 50.0", "b < 0", "id = id", "id <> id"]
+
+
+@pytest.mark.parametrize("device", [True, False], ids=["device", "host"])
+@pytest.mark.parametrize("tile_kind", [-1, 0, 1])
+def test_group_matches_per_batch_results(tile_kind, device):
+    c = chq.Context(0)
+    c.set_option("tile_kind", tile_kind)
+    recs = [fixed_batch(n, 100 + i) for i, n in enumerate(RAGGED)]
+    for sql in PREDICATES:
+        st = check_group(c, recs, sql, device)
+        assert st["launches"] == 2, (sql, st["launches"])   # the fused kernel + the per-batch prefix gather
+        assert st["rows_in"] == sum(RAGGED)
+    c.close()
+
+
+def test_reference_sized_batches_in_one_launch(ctx):
+    """the reference's planner emits 10 000-row batches (physical_planner.rs:323)"""
+    recs = [fixed_batch(10_000, 7 + i, with_wide=False) for i in range(40)]
+    st = check_group(ctx, recs, "value2 > 10.0", True)
+    assert st["launches"] == 2 and st["rows_in"] == 400_000
+    # the outputs are slices of one dense buffer per column: consecutive batches are adjacent in HBM
+    devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs[:3]]
+    outs = chq.filter_records(devs, empty_aliases(recs[0]), parse_expr("value2 > 10.0"), ctx=ctx)
+    a0, a1 = outs[0].column_buffer_address(0), outs[1].column_buffer_address(0)
+    assert a1 - a0 == 4 * outs[0].num_rows
+
+
+def test_group_result_outlives_its_siblings(ctx):
+    """every output batch owns a share of the dense buffers: releasing some must not disturb the others"""
+    recs = [fixed_batch(5000, 900 + i) for i in range(6)]
+    al = empty_aliases(recs[0])
+    e = parse_expr("value1 > 0.0")
+    devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]
+    outs = chq.filter_records(devs, al, e, ctx=ctx)
+    keep = outs[4]
+    for i, o in enumerate(outs):
+        if i != 4:
+            o.release()
+    del outs
+    junk = [chq.DeviceRecordBatch.from_host(fixed_batch(5000, 5), ctx) for _ in range(4)]   # would reuse freed blocks
+    assert batches_identical(keep.to_host(), O.filter_record(recs[4], al, e))
+    del junk
+
+
+@pytest.mark.parametrize("device", [True, False], ids=["device", "host"])
+def test_groups_outside_the_fast_path_take_the_loop(ctx, device):
+    """Utf8 / Boolean / nullable columns, 0- and 1-row batches, literal-only predicates: same results, batch by batch"""
+    rng = np.random.default_rng(5)
+
+    def mixed(n, seed, nulls):
+        r = np.random.default_rng(seed)
+        m = (r.random(n) < 0.2) if nulls and n else None
+        return pa.RecordBatch.from_arrays(
+            [pa.array(r.integers(0, 100, n).astype(np.int32), mask=m), pa.array(["s%d" % v for v in r.integers(0, 9, n)], type=pa.utf8()),
+             pa.array(r.integers(0, 2, n).astype(bool))], names=["a", "s", "f"])
+
+    groups = [
+        ([mixed(n, 40 + n, False) for n in (100, 3000, 17)], "a > 50 and s <> 's3'"),
+        ([mixed(n, 50 + n, True) for n in (100, 3000, 17)], "a > 50 or f"),
+        ([fixed_batch(n, 60 + n) for n in (100, 0, 1, 5000)], "value2 > 10.0"),
+        ([fixed_batch(n, 70 + n) for n in (100, 200)], "1 = 1"),
+    ]
+    del rng
+    for recs, sql in groups:
+        st = check_group(ctx, recs, sql, device)
+        assert st["launches"] >= len([r for r in recs if r.num_rows > 0])
+
+
+def test_a_single_null_moves_the_whole_group_to_the_loop(ctx):
+    recs = [fixed_batch(4000, 80 + i, with_wide=False) for i in range(4)]
+    v = recs[2].column(1).to_numpy().copy()
+    mask = np.zeros(len(v), dtype=bool)
+    mask[1234] = True
+    cols = list(recs[2].columns)
+    cols[1] = pa.array(v, mask=mask)
+    recs[2] = pa.RecordBatch.from_arrays(cols, names=recs[2].schema.names)
+    for device in (True, False):
+        check_group(ctx, recs, "value1 > 5.0", device)
+
+
+def test_group_errors_are_those_of_the_earliest_failing_batch(ctx):
+    """no partial output; status and message of the first batch (array order) whose single call fails"""
+    def ints(vals):
+        return pa.RecordBatch.from_arrays([pa.array(np.asarray(vals, dtype=np.int32)), pa.array(np.arange(len(vals), dtype=np.int32))], names=["a", "d"])
+
+    ok = ints(np.arange(1, 3001))
+    overflow = ints([1, 2, 2**31 - 1] + [5] * 3000)     # a + 1 overflows
+    zero_div = ints([7] * 5000)                          # a / d: d[0] = 0 -> divide by zero
+    al = empty_aliases(ok)
+    e = parse_expr("(a + 1) / d > 0")
+    # ok batch: d[0] = 0 as well -> use a predicate that divides by a (never zero) for ok / overflow ordering
+    e2 = parse_expr("(a + 1) / a > 0")
+    for recs, expr in [([ok, overflow, zero_div], e2), ([ok, ints([3] * 10), overflow], e2)]:
+        codes = []
+        for r in recs:
+            try:
+                O.filter_record(r, al, expr)
+                codes.append(None)
+            except O.OracleError as err:
+                codes.append(err.code)
+        first = next(c for c in codes if c is not None)
+        for device in (True, False):
+            src = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs] if device else recs
+            with pytest.raises(chq.ChqError) as ei:
+                chq.filter_records(src, al, expr, ctx=ctx)
+            assert ei.value.code == first
+    # div-by-zero in the first batch wins over the overflow in a later one
+    with pytest.raises(chq.ChqError) as ei:
+        chq.filter_records([zero_div, overflow, ok], al, e, ctx=ctx)
+    assert ei.value.code == 21
+    # the context stays usable
+    check_group(ctx, [ok, ok], "a > 10", True)
+
+
+def test_group_static_errors_and_argument_checks(ctx):
+    recs = [fixed_batch(100, 1), fixed_batch(200, 2)]
+    al = empty_aliases(recs[0])
+    for sql in ["nope > 1", "id + 1", "id > 'x'"]:   # unknown column, not a Boolean predicate, no common type
+        with pytest.raises(O.OracleError) as xi:
+            O.filter_record(recs[0], al, parse_expr(sql))
+        for src in (recs, [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]):
+            with pytest.raises(chq.ChqError) as ei:
+                chq.filter_records(src, al, parse_expr(sql), ctx=ctx)
+            assert ei.value.code == xi.value.code, sql
+    with pytest.raises(ValueError):
+        chq.RecordGroup([], ctx)
+    with pytest.raises(ValueError):
+        chq.RecordGroup([recs[0], chq.DeviceRecordBatch.from_host(recs[1], ctx)], ctx)
+
+
+def test_large_group_many_small_batches(ctx):
+    """2 000 batches x 10 000 rows resident in HBM, wrapped zero-copy from one allocation; counts checked against numpy"""
+    import torch
+    nb, rows = 2000, 10_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cols = [torch.rand(nb * rows, generator=g, device="cuda", dtype=torch.float32) * 20.0 for _ in range(3)]
+    torch.cuda.synchronize()
+    devs = []
+    for b in range(nb):
+        devs.append(chq.DeviceRecordBatch.from_device_pointers(
+            [(name, "f", c.data_ptr() + 4 * b * rows) for name, c in zip(("id", "value1", "value2"), cols)], rows, ctx))
+    grp = chq.RecordGroup(devs, ctx)
+    e = parse_expr("value2 > 10.0")
+    outs = chq.filter_records(grp, [[], [], []], e, ctx=ctx)
+    st = ctx.last_stats()
+    assert st["launches"] == 2 and st["rows_in"] == nb * rows
+    mask = cols[2] > 10.0
+    exp_counts = mask.view(nb, rows).sum(dim=1).cpu().numpy()
+    assert [o.num_rows for o in outs] == exp_counts.tolist()
+    total = int(exp_counts.sum())
+    for k in range(3):
+        exp = torch.masked_select(cols[k], mask)
+        base = outs[0].column_buffer_address(k)
+        got = torch.empty(total, dtype=torch.float32, device="cuda")
+        _dtod(got, base, 4 * total)
+        assert torch.equal(got, exp)
+    # spot-check a few batches through the ordinary export path
+    for b in (0, 777, nb - 1):
+        h = outs[b].to_host()
+        lo, hi = b * rows, (b + 1) * rows
+        assert np.array_equal(h.column(2).to_numpy(), cols[2][lo:hi][mask[lo:hi]].cpu().numpy())
