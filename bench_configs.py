@@ -185,6 +185,25 @@ def main():
             if it:
                 fk.append(st["kernel_ns"] / 1e6); wall.append((t1 - t0) * 1e3)
         fk.sort(); wall.sort()
+        # the C call alone (no Python per-batch work): arguments prepared, outputs released afterwards through C callbacks
+        import ctypes as C
+        from chapterhouseqe_amd import _lib as L
+        from chapterhouseqe_amd.record_utils import _Aliases, _expr_to_c
+        ce, cal = _expr_to_c(pred), _Aliases(al)
+        ccall, crel = [], []
+        for it in range(3):
+            outs = (L.ArrowDeviceArray * nb)(); schemas = (L.ArrowSchema * nb)()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = L.lib().chq_filter_records(ctx.handle, nb, grp.ptrs, C.byref(grp.schema), cal.ptr, ce, L.ARROW_DEVICE_ROCM, outs, schemas)
+            t1 = time.perf_counter()
+            assert rc == 0
+            rel = C.CFUNCTYPE(None, C.c_void_p)
+            for i in range(nb):
+                rel(outs[i].array.release)(C.addressof(outs[i].array)); rel(schemas[i].release)(C.addressof(schemas[i]))
+            t2 = time.perf_counter()
+            ccall.append((t1 - t0) * 1e3); crel.append((t2 - t1) * 1e3)
+        L.lib().chq_expr_free(ce)
         # the per-batch loop on a subset, same batches
         sub = min(nb, 2000)
         torch.cuda.synchronize()
@@ -198,6 +217,7 @@ def main():
              "tiles": st["tiles"], "alg_bytes": alg, "group_kernel_GBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9,
              "group_kernel_frac_of_8TBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9 / HBM_PEAK,
              "rows_per_s_group_call": n / (wall[len(wall) // 2] * 1e-3),
+             "c_call_ms": min(ccall), "rows_per_s_c_call": n / (min(ccall) * 1e-3), "python_release_ms": min(crel),
              "per_batch_loop_us_per_batch": loop_s / sub * 1e6, "rows_per_s_per_batch_loop": sub * rows_per_batch / loop_s,
              "wrap_inputs_s": wrap_s, "note": note}
         results.append(r)

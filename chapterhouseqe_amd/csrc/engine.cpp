@@ -797,7 +797,11 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   int tile_kind;
   if (lw.wide || lw.num_temps > 0) tile_kind = 2;
   else if (ctx.opt_tile_kind >= 0) tile_kind = (int)ctx.opt_tile_kind;
-  else tile_kind = (total_rows / (int64_t)nb) >= 6144 ? 0 : 1;
+  else {   // the large tile unless padding every batch to a multiple of it idles more than a quarter of the lanes
+    int64_t padded = 0;
+    for (const Batch& r : recs) padded += (r.nrows + kTileRows[0] - 1) / kTileRows[0] * kTileRows[0];
+    tile_kind = padded * 4 <= total_rows * 5 ? 0 : 1;
+  }
   const int64_t tile_rows = kTileRows[tile_kind];
   int64_t ntiles = 0;
   for (const Batch& r : recs) ntiles += (r.nrows + tile_rows - 1) / tile_rows;
@@ -853,7 +857,6 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   p.status = dev_status(ctx);
   p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
   fill_refs(p.pb, lw, recs[0], {});
-  p.pb.fast_kind = FAST_NONE;
   for (size_t k = 0; k < nout; ++k) {
     p.outs[k].in = nullptr; p.outs[k].out = dense[launch_cols[k]]->ptr; p.outs[k].width = (uint32_t)recs[0].cols[launch_cols[k]].width;
   }

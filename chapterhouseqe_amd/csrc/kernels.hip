@@ -231,13 +231,18 @@ struct Interp {
       else fetch_values<true>(c, c.values, l, h);
     } else {
       const void* vals = ptr_row ? (const void*)ptr_row[ref_idx] : c.values;
+      if (nact == 64 * R && c.type != T_BOOL) {
+        // a complete wave inside an incomplete tile (or a batch-group launch): same code as the FULL instantiation
+        fetch_values<true>(c, vals, l, h);
+      } else {
 #pragma unroll
-      for (int j = 0; j < R; ++j) l[j] = 0;
+        for (int j = 0; j < R; ++j) l[j] = 0;
 #pragma unroll
-      for (int j = 0; j < RH; ++j) h[j] = 0;
-      if (nact > 0) {
-        if (c.type == T_BOOL) b = fetch_flags(vals, c.bool_bit_offset);
-        else fetch_values<false>(c, vals, l, h);
+        for (int j = 0; j < RH; ++j) h[j] = 0;
+        if (nact > 0) {
+          if (c.type == T_BOOL) b = fetch_flags(vals, c.bool_bit_offset);
+          else fetch_values<false>(c, vals, l, h);
+        }
       }
     }
     v = c.validity ? (fetch_flags(c.validity, c.validity_bit_offset) & actv) : actv;
@@ -470,10 +475,10 @@ struct Interp {
     bitsv = r & actv;
   }
 
-  // ---- specialised shape: 32-bit column <cmp> literal (FAST_CMP_CONST), full waves only ------------------
+  // ---- specialised shape: 32-bit column <cmp> literal (FAST_CMP_CONST), complete waves only ------------------
   __device__ __forceinline__ void run_cmp_const(const ProgramBlock& pb) {
     const Instr cmp = pb.prog[1];
-    const uint32_t* src = (const uint32_t*)pb.refs[0].values + w0;
+    const uint32_t* src = (const uint32_t*)((PARTIAL && ptr_row) ? (const void*)ptr_row[0] : pb.refs[0].values) + w0;
     uint32_t v[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) v[j] = src[j * 64 + lane];
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     }
     it.set_rows(row0, nr, lane, wv);
     if (p.stash_ref >= 0) { it.stash = s_stash[buf]; it.stash_ref = p.stash_ref; }
-    if (!PARTIAL && p.pb.fast_kind == FAST_CMP_CONST) it.run_cmp_const(p.pb);
+    if (p.pb.fast_kind == FAST_CMP_CONST && it.nact == 64 * R) it.run_cmp_const(p.pb);
     else it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE, PARTIAL>&) {});
     const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
     s_sel[buf][tid] = selv;
@@ -810,7 +815,10 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 #undef LOAD_IDX
       }
     };
-    copy_columns(std::integral_constant<bool, !PARTIAL>{});
+    if constexpr (PARTIAL) {
+      if (nact == 64 * R) copy_columns(std::true_type{});   // complete wave: unclamped, immediate-offset loads
+      else copy_columns(std::false_type{});
+    } else copy_columns(std::true_type{});
     if (p.stash_ref >= 0 && !(p.debug & 2)) {   // the predicate column: values are still in LDS
       const OutCol oc = p.outs[p.n_out - 1];
       const uint32_t* sv = s_stash[buf] + tid;
