@@ -31,55 +31,80 @@ static size_t size_class(size_t bytes) {
   const size_t g = 2u << 20;
   return (bytes + g - 1) / g * g;
 }
-void* DevicePool::alloc(size_t bytes, int device) {
+static uint64_t pool_key(size_t cap, int device) { return ((uint64_t)cap << 8) | (uint64_t)(device & 0xff); }
+void* DevicePool::alloc(size_t bytes, int device, size_t* cap_out) {
   const size_t cap = size_class(bytes);
+  *cap_out = cap;
   {
     std::lock_guard<std::mutex> lk(mu_);
-    for (size_t i = 0; i < free_.size(); ++i) {
-      if (free_[i].cap == cap && free_[i].device == device) {
-        Block b = free_[i];
-        free_[i] = free_.back(); free_.pop_back();
-        live_.push_back(b);
-        return b.p;
-      }
-    }
+    auto it = free_.find(pool_key(cap, device));
+    if (it != free_.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); return p; }
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, cap);
   if (e == hipErrorOutOfMemory) { trim(); e = hipMalloc(&p, cap); }
   check_hip(e, "hipMalloc");
-  std::lock_guard<std::mutex> lk(mu_);
-  live_.push_back(Block{p, cap, device});
   return p;
 }
-void DevicePool::free(void* p) {
+void DevicePool::free(void* p, size_t cap, int device) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(mu_);
-  for (size_t i = 0; i < live_.size(); ++i) {
-    if (live_[i].p == p) { free_.push_back(live_[i]); live_[i] = live_.back(); live_.pop_back(); return; }
-  }
+  free_[pool_key(cap, device)].push_back(p);
 }
 void DevicePool::trim() {
-  std::vector<Block> f;
+  std::unordered_map<uint64_t, std::vector<void*>> f;
   { std::lock_guard<std::mutex> lk(mu_); f.swap(free_); }
-  for (auto& b : f) (void)hipFree(b.p);
+  for (auto& kv : f) for (void* p : kv.second) (void)hipFree(p);
+}
+
+HostPool& HostPool::instance() {
+  static HostPool* pool = new HostPool();   // leaked on purpose, like the device pool
+  return *pool;
+}
+void* HostPool::alloc(size_t bytes, size_t* cap_out) {
+  const size_t cap = size_class(bytes < 64 ? 64 : bytes);
+  *cap_out = cap;
+  if (cap >= ((size_t)1 << 20)) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = free_.find(cap);
+    if (it != free_.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); cached_ -= cap; return p; }
+  }
+  void* p = nullptr;
+  if (posix_memalign(&p, 64, cap) != 0) throw ChqError{CHQ_ERR_OUT_OF_MEMORY, "host allocation failed"};
+  return p;
+}
+void HostPool::free(void* p, size_t cap) {
+  if (!p) return;
+  if (cap >= ((size_t)1 << 20)) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (cached_ + cap <= limit_) { free_[cap].push_back(p); cached_ += cap; return; }
+  }
+  ::free(p);
+}
+void HostPool::trim() {
+  std::unordered_map<size_t, std::vector<void*>> f;
+  { std::lock_guard<std::mutex> lk(mu_); f.swap(free_); cached_ = 0; }
+  for (auto& kv : f) for (void* p : kv.second) ::free(p);
+}
+void HostPool::set_limit(size_t bytes) {
+  { std::lock_guard<std::mutex> lk(mu_); limit_ = bytes; }
+  if (bytes == 0) trim();
 }
 
 Buffer::~Buffer() {
   if (!ptr) return;
-  if (device) DevicePool::instance().free(ptr); else ::free(ptr);
+  if (device) DevicePool::instance().free(ptr, cap, device_id); else HostPool::instance().free(ptr, cap);
 }
 BufferPtr make_device_buffer(size_t bytes, int device) {
   auto b = std::make_shared<Buffer>();
-  b->ptr = DevicePool::instance().alloc(bytes ? bytes : 1, device);
-  b->bytes = bytes; b->device = true;
+  b->ptr = DevicePool::instance().alloc(bytes ? bytes : 1, device, &b->cap);
+  b->bytes = bytes; b->device = true; b->device_id = device;
   return b;
 }
 BufferPtr make_host_buffer(size_t bytes) {
   auto b = std::make_shared<Buffer>();
-  void* p = nullptr;
-  if (posix_memalign(&p, 64, ((bytes ? bytes : 1) + 63) / 64 * 64) != 0) throw ChqError{CHQ_ERR_OUT_OF_MEMORY, "host allocation failed"};
-  b->ptr = p; b->bytes = bytes; b->device = false;
+  b->ptr = HostPool::instance().alloc(bytes ? bytes : 1, &b->cap);
+  b->bytes = bytes; b->device = false;
   return b;
 }
 
@@ -774,20 +799,20 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   std::vector<BufferPtr> staged;
   std::vector<std::vector<const uint8_t*>> in_ptr(nb, std::vector<const uint8_t*>(ncols));
   if (host_in) {
-    std::vector<uint8_t> pack;
     for (size_t i = 0; i < ncols; ++i) {
       const int64_t w = recs[0].cols[i].width;
-      pack.resize((size_t)(total_rows * w));
+      auto pack = make_host_buffer((size_t)(total_rows * w) + 16);   // recycled block: no page faults
       auto db = make_device_buffer((size_t)(total_rows * w) + 16, ctx.device);
       int64_t at = 0;
       for (size_t b = 0; b < nb; ++b) {
-        memcpy(pack.data() + at, recs[b].cols[i].values0(), (size_t)(recs[b].nrows * w));
+        memcpy((uint8_t*)pack->ptr + at, recs[b].cols[i].values0(), (size_t)(recs[b].nrows * w));
         in_ptr[b][i] = (const uint8_t*)db->ptr + at;
         at += recs[b].nrows * w;
       }
-      check_hip(hipMemcpy(db->ptr, pack.data(), (size_t)at, hipMemcpyHostToDevice), "upload packed column");
-      staged.push_back(db);
+      check_hip(hipMemcpyAsync(db->ptr, pack->ptr, (size_t)at, hipMemcpyHostToDevice, ctx.stream), "upload packed column");
+      staged.push_back(db); staged.push_back(pack);
     }
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   } else {
     for (size_t b = 0; b < nb; ++b)
       for (size_t i = 0; i < ncols; ++i) in_ptr[b][i] = (const uint8_t*)recs[b].cols[i].values0();

@@ -6,6 +6,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/chq.h"
@@ -31,20 +32,37 @@ hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
 class DevicePool {
  public:
   static DevicePool& instance();
-  void* alloc(size_t bytes, int device);
-  void free(void* p);
+  void* alloc(size_t bytes, int device, size_t* cap);
+  void free(void* p, size_t cap, int device);
   void trim();
  private:
-  struct Block { void* p; size_t cap; int device; };
   std::mutex mu_;
-  std::vector<Block> free_;
-  std::vector<Block> live_;
+  std::unordered_map<uint64_t, std::vector<void*>> free_;   // (size class, device) -> cached blocks
+};
+
+// The same for host memory handed out as result buffers.  A fresh host allocation costs a page fault per 4 KiB the
+// first time the D2H copy touches it (measured: 8.8 GB/s instead of 55 GB/s); recycled blocks are already mapped.
+// Only blocks >= 1 MiB are cached, up to `limit` bytes in total; the rest goes straight back to the C allocator.
+class HostPool {
+ public:
+  static HostPool& instance();
+  void* alloc(size_t bytes, size_t* cap);
+  void free(void* p, size_t cap);
+  void trim();
+  void set_limit(size_t bytes);
+ private:
+  std::mutex mu_;
+  std::unordered_map<size_t, std::vector<void*>> free_;
+  size_t cached_ = 0;
+  size_t limit_ = (size_t)8 << 30;
 };
 
 // One allocation (device or host) owned by an exported batch.
 struct Buffer {
   void* ptr = nullptr;
   size_t bytes = 0;
+  size_t cap = 0;          // size class the pool handed out
+  int device_id = 0;
   bool device = false;
   ~Buffer();
   Buffer() = default;

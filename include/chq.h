@@ -86,7 +86,8 @@ const char* chq_ctx_last_error(const chq_ctx* ctx);
 /* hipStream_t the context launches on. */
 void* chq_ctx_stream(const chq_ctx* ctx);
 /* Options: "tile_kind" (-1 auto, 0: 16384-row tiles, 1/2: 2048-row tiles), "enable_minus",
- * "time_kernels", "trim_pool". Unknown keys fail. */
+ * "time_kernels", "trim_pool" (return every cached HBM / host block to the system), "host_pool_bytes" (cap of the
+ * process-wide cache of host result buffers, default 8 GiB, 0 disables it). Unknown keys fail. */
 chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value);
 /* Counters of the last filter call: rows in, rows out, tiles, kernel launches. */
 typedef struct chq_call_stats {
