@@ -160,6 +160,21 @@ def main():
             j = json.load(open(pmc))
             traffic = j["fetch_bytes_corrected"] + j["write_bytes"]
             traffic_src = "profiles/r1/bench_pmc_hbm_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)"
+        # a plain device copy measured in this same process, so the fraction is not hostage to the datasheet peak
+        # (SURVEY.md section 8 d): one column copied into a scratch tensor, read + write bytes / time
+        copy_gbps = None
+        try:
+            dst = torch.empty_like(cols[0])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dst.copy_(cols[0]); torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                dst.copy_(cols[0])
+            e1.record(); torch.cuda.synchronize()
+            copy_gbps = 2 * cols[0].numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del dst
+        except RuntimeError:
+            pass
         out = {
             "metric": "filtered rows/sec (input rows), SELECT * WHERE value2 > 10.0, 3 x f32, device-resident",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -175,7 +190,9 @@ def main():
                          "kernel": "filter_fused_kernel<1024,16,FULL> (+ one-workgroup launch for the partial tail tile)",
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "read_frac_of_peak": (stats["bytes_read_alg"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_ms > 0 else None},
+                         "read_frac_of_peak": (stats["bytes_read_alg"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if kern_ms > 0 else None,
+                         "device_copy_GBps_same_run": copy_gbps,
+                         "frac_of_device_copy": (achieved / copy_gbps) if (achieved and copy_gbps) else None},
         }
         if not args.no_cpu_baseline:
             import pyarrow as pa
@@ -187,6 +204,28 @@ def main():
                                    "sample": f"first {m} rows of the same columns, 10 000-row batches, one thread = one "
                                              f"operator instance (filter_task.rs:86-125), {secs:.1f} s, kept {kept} rows",
                                    "host_cpus": os.cpu_count()}
+            # (ii) one instance per host core over disjoint slices of the same rows (the C oracle runs outside the GIL)
+            import threading
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            T = max(1, min(ncpu, 64))
+            if T > 1:
+                per = (m // T) // 10_000 * 10_000
+                if per > 0:
+                    kept_t = [0] * T
+                    def work(i):
+                        kept_t[i] = O.filter_table_batched(host.slice(i * per, per), aliases, expr, batch_rows=10_000)[0]
+                    ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+                    w0 = time.perf_counter()
+                    for th in ths:
+                        th.start()
+                    for th in ths:
+                        th.join()
+                    wsecs = time.perf_counter() - w0
+                    out["cpu_baseline"]["all_cores"] = {"value": per * T / wsecs, "unit": "rows/s", "cores": T,
+                                                        "sample": f"{T} threads x {per} rows, {wsecs:.1f} s wall, kept {sum(kept_t)} rows"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

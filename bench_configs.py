@@ -242,6 +242,8 @@ def main():
     n4 = max(1024, int(20_000_000 * args.scale))
     run_case("config4b wide strings id>n/2 (s~0.5)", 20_000_000, c4, f"id > {n4 // 2}", seed=4)
     run_case("config4c wide strings value2<10 (s~0.1)", 20_000_000, c4, "value2 < 10.0", seed=4)
+    run_case("config4d wide strings value1>='n' (Utf8 predicate, s~0.5)", 20_000_000, c4, "value1 >= 'n'", seed=4)
+    run_case("config4e wide strings value1<'b' (Utf8 predicate, s~0.04)", 20_000_000, c4, "value1 < 'b'", seed=4)
     c5 = [("id", "id"), ("value1", "utf8", 8), ("value2", "f32", 0, 100)]
     run_case("config5-shape id%2=0, one record batch", 250_000_000, c5, "id % 2 = 0", seed=5,
              note="huge_simple.sql shape; one Utf8 array holds < 2 GiB of bytes (int32 offsets), so a 1.25 B-row GPU shard is "
