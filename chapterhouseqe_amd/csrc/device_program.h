@@ -125,8 +125,15 @@ struct FilterParams {
   // straddle batches; row `tile` of this table (group_stride words) = { first row of the tile inside its batch, rows of
   // that batch, value pointers of the n_refs program inputs, input pointers of the n_out copied columns }.
   // nullptr = single batch (pointers come from pb.refs / outs, rows are tile * TILE).  PARTIAL instantiation only.
+  // Near-uniform groups (the reference's fixed 10 000-row batches) are packed at WAVE granularity instead
+  // (group_wpb > 0): every batch owns group_wpb consecutive waves, so a tile's waves may belong to different batches
+  // and no lanes idle behind a batch end.  Row b of the table = { rows of batch b, the same pointers }, wave w serves
+  // batch w / group_wpb, and the last wave of a batch stores the batch's end offset in group_batch_end[b].
   const u64* group;
   int64_t group_stride;
+  int32_t group_wpb;
+  int32_t group_nb;
+  u64* group_batch_end;
   ProgramBlock pb;
   OutCol outs[MAX_OUT];
 };

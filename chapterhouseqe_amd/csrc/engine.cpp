@@ -819,17 +819,33 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   }
 
   // ---- tiling ------------------------------------------------------------------------------------------------
+  // Wave-granular packing when the batches are near-uniform (every batch gets the wave count of the longest one and
+  // at most a fifth of the waves idle); otherwise whole tiles per batch, described by a per-tile table.
+  constexpr int64_t kWaveRows[3] = {64 * 16, 64 * 8, 64 * 8};
+  constexpr int64_t kWavesPerTile[3] = {16, 4, 4};
   int tile_kind;
+  int64_t wpb = 0;   // > 0: wave-granular mode
   if (lw.wide || lw.num_temps > 0) tile_kind = 2;
   else if (ctx.opt_tile_kind >= 0) tile_kind = (int)ctx.opt_tile_kind;
-  else {   // the large tile unless padding every batch to a multiple of it idles more than a quarter of the lanes
+  else tile_kind = -1;
+  {
+    const int k = tile_kind < 0 ? 0 : tile_kind;
+    const int64_t w = (max_rows + kWaveRows[k] - 1) / kWaveRows[k];
+    if (ctx.opt_group_mode != 1 && w * (int64_t)nb * kWaveRows[k] * 4 <= total_rows * 5 && w * (int64_t)nb < (1ll << 31) - 64) {
+      wpb = w; tile_kind = k;
+    } else if (ctx.opt_group_mode == 2) {
+      wpb = w; tile_kind = k;
+    }
+  }
+  if (tile_kind < 0) {   // the large tile unless padding every batch to a multiple of it idles more than a quarter of the lanes
     int64_t padded = 0;
     for (const Batch& r : recs) padded += (r.nrows + kTileRows[0] - 1) / kTileRows[0] * kTileRows[0];
     tile_kind = padded * 4 <= total_rows * 5 ? 0 : 1;
   }
   const int64_t tile_rows = kTileRows[tile_kind];
   int64_t ntiles = 0;
-  for (const Batch& r : recs) ntiles += (r.nrows + tile_rows - 1) / tile_rows;
+  if (wpb > 0) ntiles = (wpb * (int64_t)nb + kWavesPerTile[tile_kind] - 1) / kWavesPerTile[tile_kind];
+  else for (const Batch& r : recs) ntiles += (r.nrows + tile_rows - 1) / tile_rows;
   ensure_scratch(ctx, ntiles);
   Scratch* ds = dev_scratch(ctx);
 
@@ -847,20 +863,26 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
     }
   }
   const size_t nrefs = lw.refs.size(), nout = launch_cols.size();
-  const size_t stride = 2 + nrefs + nout;
+  const size_t stride = (wpb > 0 ? 1 : 2) + nrefs + nout;
 
-  // ---- tile table + index of every batch's last tile: built in pinned memory, one upload ---------------------
-  const size_t tbl_words = (size_t)ntiles * stride;
-  const size_t bytes_tbl = tbl_words * 8, bytes_idx = nb * 8, bytes_cnt = nb * 8;
+  // ---- table (+ index of every batch's last tile in tile mode): built in pinned memory, one upload ---------------
+  const size_t tbl_words = (wpb > 0 ? nb : (size_t)ntiles) * stride;
+  const size_t bytes_tbl = tbl_words * 8, bytes_idx = wpb > 0 ? 0 : nb * 8, bytes_cnt = nb * 8;
   ensure_pinned_table(ctx, bytes_tbl + bytes_idx + bytes_cnt);
   u64* h_tbl = (u64*)ctx.pinned_tbl;
   int64_t* h_idx = (int64_t*)(h_tbl + tbl_words);
-  u64* h_cnt = (u64*)(h_idx + nb);
+  u64* h_cnt = (u64*)((uint8_t*)h_tbl + bytes_tbl + bytes_idx);
   {
     u64* w = h_tbl;
     int64_t tile = 0;
     for (size_t b = 0; b < nb; ++b) {
       const int64_t rows = recs[b].nrows;
+      if (wpb > 0) {
+        *w++ = (u64)rows;
+        for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
+        for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
+        continue;
+      }
       for (int64_t r0 = 0; r0 < rows; r0 += tile_rows, ++tile) {
         *w++ = (u64)r0; *w++ = (u64)rows;
         for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
@@ -870,7 +892,8 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
     }
   }
   auto d_tbl = make_device_buffer(bytes_tbl + bytes_idx + bytes_cnt + 16, ctx.device);
-  check_hip(hipMemcpyAsync(d_tbl->ptr, h_tbl, bytes_tbl + bytes_idx, hipMemcpyHostToDevice, ctx.stream), "upload tile table");
+  check_hip(hipMemcpyAsync(d_tbl->ptr, h_tbl, bytes_tbl + bytes_idx, hipMemcpyHostToDevice, ctx.stream), "upload group table");
+  u64* d_cnt = (u64*)((uint8_t*)d_tbl->ptr + bytes_tbl + bytes_idx);
 
   // ---- dense outputs ---------------------------------------------------------------------------------------
   std::vector<BufferPtr> dense(ncols);
@@ -888,6 +911,7 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   p.n_out = (int16_t)nout;
   p.debug = (int32_t)(ctx.opt_debug & ~1);
   p.group = (const u64*)d_tbl->ptr; p.group_stride = (int64_t)stride;
+  p.group_wpb = (int32_t)wpb; p.group_nb = (int32_t)nb; p.group_batch_end = d_cnt;
   p.tile_begin = 0; p.tile_end = ntiles;
   check_hip(hipMemsetAsync(ds, 0, kHeader + (size_t)(ntiles + 1) * 8, ctx.stream), "memset scratch + status");
   const int grid_cap = ctx.num_cus * (ctx.opt_grid_per_cu > 0 ? (int)ctx.opt_grid_per_cu : kGridPerCu[tile_kind]);
@@ -895,14 +919,17 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   if (ctx.opt_time_kernels) check_hip(hipEventRecord(ctx.ev0, ctx.stream), "hipEventRecord");
   check_hip(launch_filter(p, tile_kind, true, (int)std::min<int64_t>(ntiles, grid_cap), ctx.stream), "launch filter_fused_kernel (group)");
   if (ctx.opt_time_kernels) check_hip(hipEventRecord(ctx.ev1, ctx.stream), "hipEventRecord");
-  GatherStatusParams gp{};
-  gp.status = dev_status(ctx); gp.idx = (const int64_t*)((const uint8_t*)d_tbl->ptr + bytes_tbl);
-  gp.dst = (u64*)((uint8_t*)d_tbl->ptr + bytes_tbl + bytes_idx); gp.n = (int64_t)nb;
-  check_hip(launch_gather_status(gp, ctx.stream), "launch gather_status_kernel");
-  ctx.stats.launches = 2; ctx.stats.tiles = ntiles;
+  ctx.stats.launches = 1; ctx.stats.tiles = ntiles;
+  if (wpb == 0) {   // tile mode: the inclusive prefix at every batch's last tile
+    GatherStatusParams gp{};
+    gp.status = dev_status(ctx); gp.idx = (const int64_t*)((const uint8_t*)d_tbl->ptr + bytes_tbl);
+    gp.dst = d_cnt; gp.n = (int64_t)nb;
+    check_hip(launch_gather_status(gp, ctx.stream), "launch gather_status_kernel");
+    ctx.stats.launches = 2;
+  }
   Scratch* hs = (Scratch*)ctx.pinned;
   check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
-  check_hip(hipMemcpyAsync(h_cnt, gp.dst, bytes_cnt, hipMemcpyDeviceToHost, ctx.stream), "read back batch prefixes");
+  check_hip(hipMemcpyAsync(h_cnt, d_cnt, bytes_cnt, hipMemcpyDeviceToHost, ctx.stream), "read back batch prefixes");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
   if (hs->err != ERR_NONE) return per_batch_loop();   // reports the earliest failing batch, as the reference's loop would

@@ -117,6 +117,7 @@ struct Context {
   bool opt_stash = true;
   int64_t opt_grid_per_cu = 0;
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
+  int64_t opt_group_mode = 0;       // batch-group launch: 0 auto, 1 force per-tile table, 2 force wave-granular packing
   int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // reusable device scratch

@@ -31,6 +31,26 @@ namespace chq {
 #define ST_VAL(x) ((x) & ((1ULL << 62) - 1))
 #define ST_FLAG(x) ((x) >> 62)
 
+// ------------------------------------------------------------------------------------------------
+// Bounds-checked loads for incomplete waves: a raw buffer resource over the wave's rows [w0, w0 + nact) of one
+// column; lanes past the end read 0 from the hardware range check instead of paying for clamped addresses.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rows_rsrc(const void* col, int64_t w0, int width, int nact) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)col + w0 * width), 0, nact * width, 0x00020000);
+}
+template <typename TY> __device__ __forceinline__ TY buf_load(__amdgpu_buffer_rsrc_t r, int elem);
+template <> __device__ __forceinline__ uint8_t buf_load<uint8_t>(__amdgpu_buffer_rsrc_t r, int e) { return __builtin_amdgcn_raw_buffer_load_b8(r, e, 0, 0); }
+template <> __device__ __forceinline__ int8_t buf_load<int8_t>(__amdgpu_buffer_rsrc_t r, int e) { return (int8_t)__builtin_amdgcn_raw_buffer_load_b8(r, e, 0, 0); }
+template <> __device__ __forceinline__ uint16_t buf_load<uint16_t>(__amdgpu_buffer_rsrc_t r, int e) { return __builtin_amdgcn_raw_buffer_load_b16(r, e * 2, 0, 0); }
+template <> __device__ __forceinline__ int16_t buf_load<int16_t>(__amdgpu_buffer_rsrc_t r, int e) { return (int16_t)__builtin_amdgcn_raw_buffer_load_b16(r, e * 2, 0, 0); }
+template <> __device__ __forceinline__ uint32_t buf_load<uint32_t>(__amdgpu_buffer_rsrc_t r, int e) { return __builtin_amdgcn_raw_buffer_load_b32(r, e * 4, 0, 0); }
+template <> __device__ __forceinline__ uint2 buf_load<uint2>(__amdgpu_buffer_rsrc_t r, int e) {
+  const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, e * 8, 0, 0); return make_uint2(v.x, v.y); }
+template <> __device__ __forceinline__ uint4 buf_load<uint4>(__amdgpu_buffer_rsrc_t r, int e) {
+  const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(r, e * 16, 0, 0); return make_uint4(v.x, v.y, v.z, v.w); }
+
 __device__ __forceinline__ void st_store(u64* p, u64 v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -196,32 +216,57 @@ struct Interp {
   template <bool FULL>
   __device__ __forceinline__ void fetch_values(const ColRef& cr, const void* values, uint32_t (&l)[R], uint32_t (&h)[RH]) {
     struct { int type; const void* values; } c{cr.type, values};
-    // FULL: the wave's 64*R rows are all inside the batch -> element j*64+lane, no clamping (immediate offsets)
-#define IDX(j) (FULL ? (j) * 64 + lane : off(j))
-    switch (c.type) {
-      case T_I8: { const int8_t* p = (const int8_t*)c.values + w0;
+    // FULL: the wave's 64*R rows are all inside the batch -> element j*64+lane, immediate offsets off an SGPR base.
+    // Otherwise (nact > 0 rows): range-checked buffer loads, rows past the end read as 0.
+    if constexpr (FULL) {
+      switch (c.type) {
+        case T_I8: { const int8_t* p = (const int8_t*)c.values + w0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[IDX(j)]; } break;
-      case T_U8: { const uint8_t* p = (const uint8_t*)c.values + w0;
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[j * 64 + lane]; } break;
+        case T_U8: { const uint8_t* p = (const uint8_t*)c.values + w0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) l[j] = p[IDX(j)]; } break;
-      case T_I16: { const int16_t* p = (const int16_t*)c.values + w0;
+          for (int j = 0; j < R; ++j) l[j] = p[j * 64 + lane]; } break;
+        case T_I16: { const int16_t* p = (const int16_t*)c.values + w0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[IDX(j)]; } break;
-      case T_U16: { const uint16_t* p = (const uint16_t*)c.values + w0;
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)p[j * 64 + lane]; } break;
+        case T_U16: { const uint16_t* p = (const uint16_t*)c.values + w0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) l[j] = p[IDX(j)]; } break;
-      case T_I32: case T_U32: case T_F32: { const uint32_t* p = (const uint32_t*)c.values + w0;
+          for (int j = 0; j < R; ++j) l[j] = p[j * 64 + lane]; } break;
+        case T_I32: case T_U32: case T_F32: { const uint32_t* p = (const uint32_t*)c.values + w0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) l[j] = p[IDX(j)]; } break;
-      case T_I64: case T_U64: case T_F64:
-        if constexpr (WIDE) { const uint2* p = (const uint2*)c.values + w0;
+          for (int j = 0; j < R; ++j) l[j] = p[j * 64 + lane]; } break;
+        case T_I64: case T_U64: case T_F64:
+          if constexpr (WIDE) { const uint2* p = (const uint2*)c.values + w0;
 #pragma unroll
-          for (int j = 0; j < R; ++j) { uint2 x = p[IDX(j)]; l[j] = x.x; h[j] = x.y; } }
-        break;
-      default: break;
+            for (int j = 0; j < R; ++j) { uint2 x = p[j * 64 + lane]; l[j] = x.x; h[j] = x.y; } }
+          break;
+        default: break;
+      }
+    } else {
+      switch (c.type) {
+        case T_I8: { const auto r = wave_rows_rsrc(c.values, w0, 1, nact);
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)buf_load<int8_t>(r, j * 64 + lane); } break;
+        case T_U8: { const auto r = wave_rows_rsrc(c.values, w0, 1, nact);
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = buf_load<uint8_t>(r, j * 64 + lane); } break;
+        case T_I16: { const auto r = wave_rows_rsrc(c.values, w0, 2, nact);
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)buf_load<int16_t>(r, j * 64 + lane); } break;
+        case T_U16: { const auto r = wave_rows_rsrc(c.values, w0, 2, nact);
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = buf_load<uint16_t>(r, j * 64 + lane); } break;
+        case T_I32: case T_U32: case T_F32: { const auto r = wave_rows_rsrc(c.values, w0, 4, nact);
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = buf_load<uint32_t>(r, j * 64 + lane); } break;
+        case T_I64: case T_U64: case T_F64:
+          if constexpr (WIDE) { const auto r = wave_rows_rsrc(c.values, w0, 8, nact);
+#pragma unroll
+            for (int j = 0; j < R; ++j) { uint2 x = buf_load<uint2>(r, j * 64 + lane); l[j] = x.x; h[j] = x.y; } }
+          break;
+        default: break;
+      }
     }
-#undef IDX
   }
 
   __device__ __forceinline__ void fetch_col(const ColRef& c, int ref_idx, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
@@ -665,7 +710,17 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     Interp<BLOCK, R, WIDE, PARTIAL> it;
     int64_t row0 = tile * TILE, nr = p.nrows;
     if constexpr (PARTIAL) {
-      if (p.group) {   // batch-group launch: the tile's rows and column pointers come from the tile table
+      if (p.group_wpb > 0) {   // batch-group launch, wave-granular: this wave's batch and its rows inside it
+        const uint32_t wg = (uint32_t)tile * NW + (uint32_t)wv;
+        const uint32_t b = wg / (uint32_t)p.group_wpb;
+        const uint32_t lw = wg - b * (uint32_t)p.group_wpb;
+        if (b < (uint32_t)p.group_nb) {
+          const u64* brow = p.group + (int64_t)b * p.group_stride;
+          nr = uniform64((int64_t)brow[0]);
+          it.ptr_row = brow + 1;
+          row0 = ((int64_t)lw - wv) * (64 * R);   // set_rows adds wv * 64 R back
+        } else { nr = 0; row0 = 0; it.ptr_row = p.group; }
+      } else if (p.group) {   // batch-group launch: the tile's rows and column pointers come from the tile table
         const u64* trow = p.group + tile * p.group_stride;
         row0 = uniform64((int64_t)trow[0]); nr = uniform64((int64_t)trow[1]);
         it.ptr_row = trow + 2;
@@ -717,7 +772,19 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     int64_t row0 = tile * TILE, nr = p.nrows;
     const u64* in_row = nullptr;   // batch-group launch: input pointers of the copied columns
     if constexpr (PARTIAL) {
-      if (p.group) {
+      if (p.group_wpb > 0) {
+        const uint32_t wg = (uint32_t)tile * NW + (uint32_t)wv;
+        const uint32_t b = wg / (uint32_t)p.group_wpb;
+        const uint32_t lw = wg - b * (uint32_t)p.group_wpb;
+        if (b < (uint32_t)p.group_nb) {
+          const u64* brow = p.group + (int64_t)b * p.group_stride;
+          nr = uniform64((int64_t)brow[0]);
+          in_row = brow + 1 + p.pb.n_refs;
+          row0 = ((int64_t)lw - wv) * (64 * R);
+          // the last wave of a batch knows where the batch's output ends
+          if (lw + 1 == (uint32_t)p.group_wpb && lane == 0) p.group_batch_end[b] = off0 + s_wave_cnt[buf][wv];
+        } else { nr = 0; row0 = 0; }
+      } else if (p.group) {
         const u64* trow = p.group + tile * p.group_stride;
         row0 = uniform64((int64_t)trow[0]); nr = uniform64((int64_t)trow[1]);
         in_row = trow + 2 + p.pb.n_refs;
@@ -751,12 +818,14 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         const OutCol oc = p.outs[c];
         // CH values per lane are loaded (one contiguous 64-element run per instruction), then the selected ones are
         // stored at off0 + (selected rows in earlier slots) + rank of the lane among the selected lanes of its slot
-#define LOAD_IDX(j) (FULL ? (j) * 64 + lane : (((j) * 64 + lane) < nact ? ((j) * 64 + lane) : nact - 1))
+        // complete wave: element j*64+lane off an SGPR base; incomplete wave: range-checked buffer load (0 past the end)
+#define LOADV(TY, src, rs, j) (FULL ? (src)[(j) * 64 + lane] : buf_load<TY>(rs, (j) * 64 + lane))
 #define COPY_COL(TY, CH)                                                                              \
   { const TY* src = (const TY*)in_ptr(c) + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;        \
+    const auto rs = wave_rows_rsrc(in_ptr(c), w0, sizeof(TY), nact);                                    \
     _Pragma("unroll") for (int j0 = 0; j0 < R; j0 += CH) {                                             \
       TY v[CH];                                                                                        \
-      _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) v[jj] = src[LOAD_IDX(j0 + jj)];                \
+      _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) v[jj] = LOADV(TY, src, rs, j0 + jj);            \
       _Pragma("unroll") for (int jj = 0; jj < CH; ++jj) {                                              \
         const bool sel = (selv >> (j0 + jj)) & 1;                                                      \
         const u64 m = __ballot(sel);                                                                   \
@@ -773,8 +842,9 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
             uint32_t va[R], vb[R];
             auto ld = [&](int k, uint32_t (&v)[R]) {
               const uint32_t* src = (const uint32_t*)in_ptr(k) + w0;
+              const auto rs = wave_rows_rsrc(in_ptr(k), w0, 4, nact);
 #pragma unroll
-              for (int j = 0; j < R; ++j) v[j] = src[LOAD_IDX(j)];
+              for (int j = 0; j < R; ++j) v[j] = LOADV(uint32_t, src, rs, j);
             };
             auto st = [&](int k, const uint32_t (&v)[R]) {
               uint32_t* dst = (uint32_t*)p.outs[k].out + off0;
@@ -798,9 +868,10 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           case 8: COPY_COL(uint2, (R >= 8 ? 8 : R)) break;
           default: {   // 16-byte values (decimal128 ...): named registers, a private array would be promoted to LDS
             const uint4* src = (const uint4*)in_ptr(c) + w0; uint4* dst = (uint4*)oc.out + off0; unsigned run = 0;
+            const auto rs = wave_rows_rsrc(in_ptr(c), w0, 16, nact);
 #pragma unroll
             for (int j0 = 0; j0 < R; j0 += 2) {
-              const uint4 va = src[LOAD_IDX(j0)], vb = src[LOAD_IDX(j0 + 1)];
+              const uint4 va = LOADV(uint4, src, rs, j0), vb = LOADV(uint4, src, rs, j0 + 1);
               const bool sa = (selv >> j0) & 1, sb = (selv >> (j0 + 1)) & 1;
               const u64 ma = __ballot(sa);
               if (sa) dst[run + lane_rank(ma)] = va;
@@ -812,7 +883,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           } break;
         }
 #undef COPY_COL
-#undef LOAD_IDX
+#undef LOADV
       }
     };
     if constexpr (PARTIAL) {

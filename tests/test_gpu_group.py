@@ -58,15 +58,34 @@ PREDICATES = ["value2 > 10.0", "id % 2 = 0 and value1 < 20.0", "big / 3 > h or d
 
 
 @pytest.mark.parametrize("device", [True, False], ids=["device", "host"])
+@pytest.mark.parametrize("group_mode", [0, 1, 2], ids=["auto", "tile-table", "wave-packed"])
 @pytest.mark.parametrize("tile_kind", [-1, 0, 1])
-def test_group_matches_per_batch_results(tile_kind, device):
+def test_group_matches_per_batch_results(tile_kind, group_mode, device):
+    """ragged batch sizes: auto picks the per-tile table (one launch + the per-batch prefix gather); the wave-packed
+    layout is forced as well (correct on any group, only wasteful on ragged ones)"""
     c = chq.Context(0)
     c.set_option("tile_kind", tile_kind)
+    c.set_option("group_mode", group_mode)
     recs = [fixed_batch(n, 100 + i) for i, n in enumerate(RAGGED)]
     for sql in PREDICATES:
         st = check_group(c, recs, sql, device)
-        assert st["launches"] == 2, (sql, st["launches"])   # the fused kernel + the per-batch prefix gather
+        assert st["launches"] == (1 if group_mode == 2 else 2), (sql, st["launches"])
         assert st["rows_in"] == sum(RAGGED)
+    c.close()
+
+
+@pytest.mark.parametrize("group_mode", [0, 1], ids=["auto", "tile-table"])
+@pytest.mark.parametrize("rows", [10_000, 1024, 1025, 513, 9_216, 33_000])
+def test_near_uniform_groups_are_wave_packed(rows, group_mode):
+    """same-sized batches plus shorter tails (the last batch of a file): one launch, no idle lanes behind batch ends"""
+    c = chq.Context(0)
+    c.set_option("group_mode", group_mode)
+    sizes = [rows] * 9 + [max(2, rows // 3), rows, max(2, rows - 1), 2]
+    recs = [fixed_batch(n, 300 + i) for i, n in enumerate(sizes)]
+    for sql in PREDICATES[:4]:
+        st = check_group(c, recs, sql, True)
+        if group_mode == 0 and rows >= 9_216:
+            assert st["launches"] == 1, (sql, st)
     c.close()
 
 
@@ -74,7 +93,7 @@ def test_reference_sized_batches_in_one_launch(ctx):
     """the reference's planner emits 10 000-row batches (physical_planner.rs:323)"""
     recs = [fixed_batch(10_000, 7 + i, with_wide=False) for i in range(40)]
     st = check_group(ctx, recs, "value2 > 10.0", True)
-    assert st["launches"] == 2 and st["rows_in"] == 400_000
+    assert st["launches"] == 1 and st["rows_in"] == 400_000
     # the outputs are slices of one dense buffer per column: consecutive batches are adjacent in HBM
     devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs[:3]]
     outs = chq.filter_records(devs, empty_aliases(recs[0]), parse_expr("value2 > 10.0"), ctx=ctx)
@@ -200,7 +219,7 @@ def test_large_group_many_small_batches(ctx):
     e = parse_expr("value2 > 10.0")
     outs = chq.filter_records(grp, [[], [], []], e, ctx=ctx)
     st = ctx.last_stats()
-    assert st["launches"] == 2 and st["rows_in"] == nb * rows
+    assert st["launches"] == 1 and st["rows_in"] == nb * rows
     mask = cols[2] > 10.0
     exp_counts = mask.view(nb, rows).sum(dim=1).cpu().numpy()
     assert [o.num_rows for o in outs] == exp_counts.tolist()
