@@ -59,6 +59,20 @@ class RecordHandler:
             ex.heartbeat(self.operator_id, record_id)
             return ExchangeRecord(record_id, record, aliases)
 
+    def try_next_record(self) -> Optional[ExchangeRecord]:
+        """Non-blocking pull: a record that is queued right now, else None (nothing available yet, or nothing left).
+        Not in the reference -- the GPU filter task uses it to drain the queue into one batch-group launch."""
+        if not self.inbound_exchanges:
+            raise RecordHandlerError("inbound exchanges is empty")
+        ex = self.inbound_exchanges[0]
+        got = ex.get_next_record(self.operator_id, self.operator_instance_id)
+        if got == NONE_LEFT or got == NONE_AVAILABLE:
+            return None
+        record_id, record, aliases = got
+        self.tracked_records[record_id] = 0
+        ex.heartbeat(self.operator_id, record_id)
+        return ExchangeRecord(record_id, record, aliases)
+
     def send_record_to_outbound_exchange(self, record_id: int, record: Any, table_aliases: List[List[str]]) -> None:
         if self.outbound_exchange is None:
             raise RecordHandlerError("outbound exchange is none")

@@ -111,24 +111,45 @@ class FilterConfig:
 
 
 class FilterTask:
+    """filter_task.rs:65-142.  `group_size` > 1 is the GPU extension: the task drains up to that many queued records
+    of one schema and filters them with ONE kernel launch (`record_utils.filter_records`); every output still
+    carries its input record id and is acked individually, so the exchange protocol is unchanged."""
+
     def __init__(self, op_in_config: OperatorInstanceConfig, filter_config: FilterConfig,
-                 inbound_exchanges, outbound_exchange, filter_fn=None, ctx=None):
+                 inbound_exchanges, outbound_exchange, filter_fn=None, ctx=None, group_size: int = 1):
         self.operator_instance_config = op_in_config
         self.filter_config = filter_config
         self.inbound_exchanges = inbound_exchanges
         self.outbound_exchange = outbound_exchange
         self._filter = filter_fn
         self._ctx = ctx
+        self.group_size = max(1, int(group_size))
         self.records_processed = 0
         self.rows_in = 0
         self.rows_out = 0
+        self.group_calls = 0
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = record_utils.Context(self.operator_instance_config.device_id)
+        return self._ctx
 
     def _filter_record(self, rec, aliases):
         if self._filter is not None:
             return self._filter(rec, aliases, self.filter_config.expr)
-        if self._ctx is None:
-            self._ctx = record_utils.Context(self.operator_instance_config.device_id)
-        return record_utils.filter_record(rec, aliases, self.filter_config.expr, ctx=self._ctx)
+        return record_utils.filter_record(rec, aliases, self.filter_config.expr, ctx=self._context())
+
+    def _filter_group(self, group):
+        """one library call for records that share schema, residency and table aliases; else record by record"""
+        first = group[0]
+        same = self._filter is None and len(group) > 1 and all(
+            g.table_aliases == first.table_aliases and type(g.record) is type(first.record) and
+            _schema_of(g.record) == _schema_of(first.record) for g in group[1:])
+        if not same:
+            return [self._filter_record(g.record, g.table_aliases) for g in group]
+        self.group_calls += 1
+        return record_utils.filter_records([g.record for g in group], first.table_aliases, self.filter_config.expr,
+                                           ctx=self._context())
 
     def async_main(self) -> None:
         """filter_task.rs:65-142: pull -> filter -> push (same record id) -> ack"""
@@ -137,25 +158,38 @@ class FilterTask:
             exchange_rec = rec_handler.next_record()
             if exchange_rec is None:
                 break
-            filtered_rec = self._filter_record(exchange_rec.record, exchange_rec.table_aliases)
-            rec_handler.send_record_to_outbound_exchange(exchange_rec.record_id, filtered_rec, exchange_rec.table_aliases)
-            rec_handler.complete_record(exchange_rec)
-            self.records_processed += 1
-            self.rows_in += exchange_rec.record.num_rows
-            self.rows_out += filtered_rec.num_rows
+            group = [exchange_rec]
+            while len(group) < self.group_size:
+                more = rec_handler.try_next_record()
+                if more is None:
+                    break
+                group.append(more)
+            for exchange_rec, filtered_rec in zip(group, self._filter_group(group)):
+                rec_handler.send_record_to_outbound_exchange(exchange_rec.record_id, filtered_rec, exchange_rec.table_aliases)
+                rec_handler.complete_record(exchange_rec)
+                self.records_processed += 1
+                self.rows_in += exchange_rec.record.num_rows
+                self.rows_out += filtered_rec.num_rows
         rec_handler.close()
+
+
+def _schema_of(rec):
+    if hasattr(rec, "schema"):
+        return rec.schema
+    return tuple(rec.column_names())
 
 
 class FilterTaskBuilder(TaskBuilder):
     """The GPU filter operator. Swap it in with `OperatorTaskRegistry.add_filter_task_builder` -- the planner's
     DAG and the exchanges are untouched (operator_task_registry.rs:51-57)."""
 
-    def __init__(self, filter_fn=None):
+    def __init__(self, filter_fn=None, group_size: int = 1):
         self._filter_fn = filter_fn
+        self._group_size = group_size
 
     def build(self, op_in_config, inbound_exchanges, outbound_exchange):
         task = FilterTask(op_in_config, FilterConfig.try_from(op_in_config), inbound_exchanges, outbound_exchange,
-                          filter_fn=self._filter_fn)
+                          filter_fn=self._filter_fn, group_size=self._group_size)
 
         def run():
             try:

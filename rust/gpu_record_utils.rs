@@ -111,6 +111,31 @@ pub fn filter_record(ctx: &GpuContext, rec: Arc<RecordBatch>, table_aliases: &Ve
     import(out, out_schema)
 }
 
+/// `recs.iter().map(|r| filter_record(r, ..))` in one library call: every record the exchange has queued for this
+/// operator instance is filtered by ONE kernel launch (chq_filter_records); results come back one per input, in
+/// order, so each keeps its input record_id (filter_task.rs:109).
+pub fn filter_records(ctx: &GpuContext, recs: &[Arc<RecordBatch>], table_aliases: &Vec<Vec<String>>, expr: &Expr) -> Result<Vec<RecordBatch>> {
+    if recs.is_empty() {
+        return Ok(vec![]);
+    }
+    let exported: Vec<(ArrowDeviceArray, FFI_ArrowSchema)> = recs.iter().map(|r| export(r)).collect::<Result<_>>()?;
+    let ptrs: Vec<*const ArrowDeviceArray> = exported.iter().map(|(a, _)| a as *const ArrowDeviceArray).collect();
+    let al = lower_aliases(table_aliases);
+    let ta = chq_table_aliases { columns: al.lists.as_ptr(), n_columns: al.lists.len() as i32 };
+    let e = lower_expr(expr);
+    let n = recs.len();
+    let mut outs: Vec<ArrowDeviceArray> = (0..n).map(|_| unsafe { std::mem::zeroed() }).collect();
+    let mut schemas: Vec<FFI_ArrowSchema> = (0..n).map(|_| FFI_ArrowSchema::empty()).collect();
+    let rc = unsafe {
+        chq_filter_records(ctx.0, n as i32, ptrs.as_ptr(), &exported[0].1, &ta, e, ARROW_DEVICE_CPU, outs.as_mut_ptr(), schemas.as_mut_ptr())
+    };
+    unsafe { chq_expr_free(e) };
+    if rc != 0 {
+        return Err(ctx.err(rc)); // the error of the earliest failing batch; nothing was returned
+    }
+    outs.into_iter().zip(schemas.into_iter()).map(|(a, s)| import(a, s)).collect()
+}
+
 /// record_utils::project_record on the GPU (record_projection.rs:16-76)
 pub fn project_record(ctx: &GpuContext, fields: &Vec<SelectItem>, record: Arc<RecordBatch>, table_aliases: &Vec<Vec<String>>) -> Result<RecordBatch> {
     let (in_arr, in_schema) = export(&record)?;

@@ -78,13 +78,13 @@ def test_registry_accepts_one_builder_per_task():
 
 
 # ---------------------------------------------------------------------------------------------- pipeline
-def run_pipeline(tmp_path, filter_fn, project_fn, n_filter_instances, batches, sql):
+def run_pipeline(tmp_path, filter_fn, project_fn, n_filter_instances, batches, sql, group_size=1):
     """[read_files] -> [exchange] -> [filter x N] -> [exchange] -> [materialize] (README.md:88-92 of the reference)"""
     sel = parse_select(sql)
     ex_in = ExchangeOperator("operator_p0_exchange", ["operator_p1_producer"])
     ex_mid = ExchangeOperator("operator_p1_exchange", ["operator_p2_producer"])
     reg = (OperatorTaskRegistry()
-           .add_filter_task_builder(FilterTaskBuilder(filter_fn))
+           .add_filter_task_builder(FilterTaskBuilder(filter_fn, group_size=group_size))
            .add_materialize_files_builder(MaterializeFilesTaskBuilder(str(tmp_path), project_fn), ["parquet"]))
     for rid, b in enumerate(batches):                                # the table function's job (out of scope)
         ex_in.send_record(rid, b, [[] for _ in range(b.num_columns)])
@@ -120,6 +120,22 @@ def test_filter_exchange_materialize_pipeline(tmp_path, instances):
         al = [[] for _ in range(b.num_columns)]
         exp = O.project_record(sel.projection, O.filter_record(b, al, sel.selection), al)
         got = pq.read_table(os.path.join(os.path.dirname(files[0]), f"rec_{rid}.parquet")).to_batches()
+        got = got[0] if got else exp.slice(0, 0)
+        assert got.to_pydict() == exp.to_pydict()
+
+
+def test_group_size_drains_the_queue_but_keeps_the_protocol(tmp_path):
+    """group_size > 1 (GPU extension): several queued records per pull, still one output and one ack per record id"""
+    batches = simple_batches(1000, 8, 33)
+    sql = "select id, value1 from read_files('x') where id % 3 = 0"
+    runs, mrun = run_pipeline(tmp_path, O.filter_record, O.project_record, 2, batches, sql, group_size=8)
+    assert sum(f.task.records_processed for f in runs) == len(batches)
+    assert len(mrun.task.files_written) == len(batches)
+    sel = parse_select(sql)
+    for rid, b in enumerate(batches):
+        al = [[] for _ in range(b.num_columns)]
+        exp = O.project_record(sel.projection, O.filter_record(b, al, sel.selection), al)
+        got = pq.read_table(os.path.join(os.path.dirname(mrun.task.files_written[0]), f"rec_{rid}.parquet")).to_batches()
         got = got[0] if got else exp.slice(0, 0)
         assert got.to_pydict() == exp.to_pydict()
 
