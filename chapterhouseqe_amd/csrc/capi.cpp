@@ -110,6 +110,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
     else if (k == "stash") ctx->c.opt_stash = value != 0;
+    else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }
     else if (k == "debug") ctx->c.opt_debug = value;
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
     else if (k == "split_rows") ctx->c.opt_split_rows = value;
@@ -256,6 +257,12 @@ chq_status chq_filter_project_record(chq_ctx* ctx, const chq_expr* predicate, co
     Batch in = import_batch(rec, schema);
     Batch dev = to_device(ctx->c, in);
     auto pcols = plan_columns(dev, table_aliases);
+    std::vector<chq_select_item> fused_items(fields, fields + (n_fields > 0 ? n_fields : 0));
+    Batch fused;
+    if (filter_project_fused(ctx->c, dev, pcols, predicate->e, fused_items, &fused)) {
+      finish(ctx->c, std::move(fused), out_device, out, out_schema);
+      return;
+    }
     Batch filtered = filter_record(ctx->c, dev, pcols, predicate->e);   // stays in HBM
     chq_call_stats fs = ctx->c.stats;
     auto pcols2 = plan_columns(filtered, table_aliases);

@@ -155,6 +155,26 @@ struct ProjectParams {
   ProjOut outs[MAX_PROJ];
 };
 
+// filter_project_kernel: predicate + compaction + projection of the surviving rows in one pass (the reference's
+// filter -> exchange -> materialize sequence, filter_task.rs:99 + materialize_files_task.rs:110, without the
+// intermediate batch).  Only fixed-width, null-free inputs; computed outputs are numeric.
+constexpr int MAX_FUSED_COPY = 16;
+struct FusedParams {
+  int64_t nrows;
+  int64_t tile_begin, tile_end;
+  u64* status;
+  uint32_t* ticket;
+  u64* total;
+  u64* err;
+  int32_t n_proj;         // STORE slots of `proj`
+  int32_t n_copy;         // columns passed through unchanged (identifier / wildcard select items)
+  ProgramBlock pred;      // the WHERE predicate (all rows)
+  ProgramBlock proj;      // the computed select items (evaluated for surviving rows only)
+  ProjOut outs[MAX_PROJ];
+  OutCol copies[MAX_FUSED_COPY];
+};
+static_assert(sizeof(FusedParams) <= 4096, "kernel arguments are limited to 4 KiB");
+
 // follow-up kernels driven by the selection bitmap + per-tile inclusive prefixes left in `status`
 struct BitCompactParams {   // bool values / validity bitmaps
   int64_t nrows;

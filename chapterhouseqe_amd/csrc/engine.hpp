@@ -17,6 +17,7 @@ namespace chq {
 
 // kernels.hip
 hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
+hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, hipStream_t stream);
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
@@ -115,6 +116,7 @@ struct Context {
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
   bool opt_stash = true;
+  int64_t opt_fuse = 1;             // chq_filter_project_record's single-pass kernel: 0 never, 1 when it moves clearly fewer bytes, 2 whenever possible
   int64_t opt_grid_per_cu = 0;
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
   int64_t opt_group_mode = 0;       // batch-group launch: 0 auto, 1 force per-tile table, 2 force wave-granular packing
@@ -148,6 +150,9 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
                                   const Expr& expr, bool out_on_device);
 Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_dev,
                      const std::vector<PlanColumn>& pcols);
+// filter_record + project_record in one kernel pass; false = outside its scope (or an error was flagged): run the two steps
+bool filter_project_fused(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& pred,
+                          const std::vector<chq_select_item>& fields, Batch* result);
 Column compute_value(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr,
                      bool* is_scalar);
 

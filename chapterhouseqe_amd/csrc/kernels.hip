@@ -929,6 +929,139 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// filter_project_kernel: filter_fused_kernel's scan, but C(i) evaluates the select items on the tile's surviving rows
+// and stores the results compacted -- the filtered batch itself never exists in HBM.
+//   P(i): as in filter_fused_kernel.
+//   C(i): look-back -> tile base -> the projection program runs with the active-row mask narrowed to the selected
+//         rows (so validity, and with it checked-arithmetic error reporting, only sees rows the reference's
+//         project_record would see); every STORE compacts with the same ballots / ranks as a column copy.
+// Any error word set by either phase makes the host discard the result and take the two-call path, which reports
+// the reference's error (predicate errors first, then the select items in order).
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
+__global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams p) {
+  constexpr int NW = BLOCK / 64;
+  constexpr int64_t TILE = (int64_t)BLOCK * R;
+  using I = Interp<BLOCK, R, WIDE, true>;
+  __shared__ uint32_t s_sel[2][BLOCK];
+  __shared__ unsigned s_wave_cnt[2][NW];
+  __shared__ unsigned s_tot[2];
+  __shared__ int64_t s_tile[2];
+  __shared__ u64 s_base;
+  __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t ntiles = p.tile_end;
+  const int64_t last_tile = (p.nrows + TILE - 1) / TILE - 1;
+
+  auto P = [&](int buf) {
+    if (tid == 0) s_tile[buf] = p.tile_begin + (int64_t)atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const int64_t tile = uniform64(s_tile[buf]);
+    if (tile >= ntiles) return;
+    I it;
+    it.set_rows(tile * TILE, p.nrows, lane, wv);
+    if (p.pred.fast_kind == FAST_CMP_CONST && it.nact == 64 * R) it.run_cmp_const(p.pred);
+    else it.run(p.pred, p.err, s_tmp.flags, s_tmp.num, [](int, int, I&) {});
+    const uint32_t selv = it.bitsv & it.validv;
+    s_sel[buf][tid] = selv;
+    unsigned cnt = __popc(selv);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) s_wave_cnt[buf][wv] = cnt;
+    __syncthreads();
+    if (wv == 0) {
+      unsigned c = (lane < NW) ? s_wave_cnt[buf][lane] : 0u;
+      u64 tot = wave_sum((u64)c);
+      if (lane == 0) {
+        s_tot[buf] = (unsigned)tot;
+        st_store(&p.status[tile], (tile == 0 ? ST_INC : ST_AGG) | tot);
+      }
+    }
+  };
+
+  auto C = [&](int buf) {
+    const int64_t tile = uniform64(s_tile[buf]);
+    if (wv == 0) {
+      u64 excl = 0;
+      if (tile > 0) {
+        excl = lookback_exclusive(p.status, tile, 0, lane);
+        if (lane == 0) st_store(&p.status[tile], ST_INC | (excl + s_tot[buf]));
+      }
+      if (lane == 0) { s_base = excl; if (tile == last_tile) *p.total = excl + s_tot[buf]; }
+    }
+    __syncthreads();
+    u64 off0 = s_base;
+    for (int w = 0; w < wv; ++w) off0 += s_wave_cnt[buf][w];
+    off0 = (u64)uniform64((int64_t)off0);
+    I it;
+    it.set_rows(tile * TILE, p.nrows, lane, wv);
+    if (it.nact <= 0) return;
+    const uint32_t selv = s_sel[buf][tid];
+    const int64_t w0 = it.w0;
+    const int nact = it.nact;
+    // ---- select items that are plain columns: compacting copies --------------------------------------------
+    for (int c = 0; c < p.n_copy; ++c) {
+      const OutCol oc = p.copies[c];
+#define FCOPY(TY)                                                                                     \
+  { const TY* src = (const TY*)oc.in + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;            \
+    const auto rs = wave_rows_rsrc(oc.in, w0, sizeof(TY), nact);                                       \
+    _Pragma("unroll") for (int j0 = 0; j0 < R; j0 += 4) {                                              \
+      TY v[4];                                                                                         \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                 \
+        v[jj] = nact == 64 * R ? src[(j0 + jj) * 64 + lane] : buf_load<TY>(rs, (j0 + jj) * 64 + lane); \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                               \
+        const bool sel = (selv >> (j0 + jj)) & 1;                                                      \
+        const u64 m = __ballot(sel);                                                                   \
+        if (sel) dst[run + lane_rank(m)] = v[jj];                                                      \
+        run += __popcll(m); } } }
+      static_assert(R % 4 == 0, "copy loop handles four slots per step");
+      switch (oc.width) {
+        case 1: FCOPY(uint8_t) break;
+        case 2: FCOPY(uint16_t) break;
+        case 4: FCOPY(uint32_t) break;
+        case 8: FCOPY(uint2) break;
+        default: FCOPY(uint4) break;
+      }
+#undef FCOPY
+    }
+    // ---- computed select items ----------------------------------------------------------------------------
+    if (p.n_proj > 0) {
+      it.actv &= selv;
+      it.run(p.proj, p.err, s_tmp.flags, s_tmp.num, [&](int out_idx, int acc_type, I& s) {
+        const ProjOut po = p.outs[out_idx];
+        unsigned run = 0;
+#define CSTORE(TY, EXPR)                                                                              \
+  { TY* dst = (TY*)po.values + off0;                                                                  \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                    \
+      const bool sel = (selv >> j) & 1;                                                                \
+      const u64 m = __ballot(sel);                                                                     \
+      if (sel) dst[run + lane_rank(m)] = (EXPR);                                                       \
+      run += __popcll(m); } }
+        switch (acc_type) {
+          case T_I8: case T_U8: CSTORE(uint8_t, (uint8_t)s.lo[j]) break;
+          case T_I16: case T_U16: CSTORE(uint16_t, (uint16_t)s.lo[j]) break;
+          case T_I32: case T_U32: case T_F32: CSTORE(uint32_t, s.lo[j]) break;
+          default: if constexpr (WIDE) CSTORE(uint2, make_uint2(s.lo[j], s.hi[j])) break;
+        }
+#undef CSTORE
+      });
+    }
+  };
+
+  P(0);
+  int itn = 0;
+  while (true) {
+    if (s_tile[itn & 1] >= ntiles) break;
+    P((itn + 1) & 1);
+    C(itn & 1);
+    ++itn;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // project_kernel: evaluate every SelectItem expression densely (no compaction, no inter-tile state)
 // ------------------------------------------------------------------------------------------------
 template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL>
@@ -1282,6 +1415,14 @@ hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int
     default: LF(256, 8, true, MAX_NUM_TEMPS); break;
   }
 #undef LF
+  return hipGetLastError();
+}
+hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, hipStream_t stream) {
+  switch (tile_kind) {
+    case 0: hipLaunchKernelGGL((filter_project_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
+    case 1: hipLaunchKernelGGL((filter_project_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((filter_project_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
+  }
   return hipGetLastError();
 }
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {

@@ -87,7 +87,9 @@ const char* chq_ctx_last_error(const chq_ctx* ctx);
 void* chq_ctx_stream(const chq_ctx* ctx);
 /* Options: "tile_kind" (-1 auto, 0: 16384-row tiles, 1/2: 2048-row tiles), "enable_minus",
  * "time_kernels", "trim_pool" (return every cached HBM / host block to the system), "host_pool_bytes" (cap of the
- * process-wide cache of host result buffers, default 8 GiB, 0 disables it). Unknown keys fail. */
+ * process-wide cache of host result buffers, default 8 GiB, 0 disables it), "fuse" (chq_filter_project_record's
+ * single-pass kernel: 0 never, 1 = default: when it moves clearly fewer bytes than the two steps, 2 whenever the
+ * inputs allow), "group_mode" (chq_filter_records layout: 0 auto, 1 per-tile table, 2 wave-packed). Unknown keys fail. */
 chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value);
 /* Counters of the last filter call: rows in, rows out, tiles, kernel launches. */
 typedef struct chq_call_stats {
