@@ -90,3 +90,127 @@ def recv_record(src: int, device=None) -> Tuple[int, pa.RecordBatch]:
             bufs.append(pa.py_buffer(t.cpu().numpy().tobytes()))
         arrays.append(pa.Array.from_buffers(field.type, meta["num_rows"], bufs, null_count=cm["null_count"]))
     return meta["record_id"], pa.RecordBatch.from_arrays(arrays, schema=schema)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device-resident exchange: the Arrow buffers of a batch in HBM go peer to peer (RCCL send/recv over the xGMI link
+# between the two GPUs) without touching the host; only the small JSON header is built on the CPU.
+# ---------------------------------------------------------------------------------------------------------------
+_WIDTHS = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "l": 8, "L": 8, "e": 2, "f": 4, "g": 8}
+
+
+class _HbmRange:
+    """a raw HBM range exposed to torch through __cuda_array_interface__ (zero copy); keeps its owner alive"""
+
+    def __init__(self, ptr: int, nbytes: int, owner):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        self._owner = owner
+
+
+def _as_tensor(ptr: int, nbytes: int, owner, device):
+    import torch
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_HbmRange(ptr, nbytes, owner), device=device)
+
+
+def _fixed_width(fmt: str) -> int:
+    if fmt in _WIDTHS:
+        return _WIDTHS[fmt]
+    if fmt.startswith("w:"):
+        return int(fmt[2:])
+    if fmt.startswith("d:"):
+        parts = fmt[2:].split(",")
+        return int(parts[2]) // 8 if len(parts) == 3 else 16
+    if fmt in ("tdD", "tts", "ttm"):
+        return 4
+    if fmt in ("tdm", "ttu", "ttn") or fmt.startswith("ts") or fmt.startswith("tD"):
+        return 8
+    raise ValueError(f"no fixed width for Arrow format {fmt!r}")
+
+
+def device_record_to_tensors(rec, device=None):
+    """(header, tensors): zero-copy uint8 views of every Arrow buffer of a DeviceRecordBatch, in header order.
+    Buffers are sent from element 0 to offset + length, so the receiver keeps the same Arrow offsets."""
+    import torch
+    device = device if device is not None else torch.device("cuda", rec.ctx.device_id)
+    header = {"num_rows": rec.num_rows, "columns": []}
+    tensors = []
+    for col in rec.describe_columns():
+        end = col["offset"] + rec.num_rows
+        fmt = col["format"]
+        sizes = {"validity": 0, "values": 0, "data": 0}
+        if col["validity"] and col["null_count"] != 0:
+            sizes["validity"] = (end + 7) // 8
+        if fmt == "b":
+            sizes["values"] = (end + 7) // 8
+        elif fmt == "u":
+            # offsets stay absolute: only the bytes the logical rows use, [offsets[offset], offsets[end]), are sent and
+            # the receiver rebases its data pointer by the first offset
+            sizes["values"] = 4 * (end + 1)
+            if col["values"] and rec.num_rows:
+                first = int(_as_tensor(col["values"] + 4 * col["offset"], 4, rec, device).view(torch.int32).item())
+                last = int(_as_tensor(col["values"] + 4 * end, 4, rec, device).view(torch.int32).item())
+                sizes["data"] = last - first
+                col = dict(col, data=col["data"] + first, data_base=first)
+        else:
+            sizes["values"] = _fixed_width(fmt) * end
+        for key in ("validity", "values", "data"):
+            if sizes[key]:
+                tensors.append(_as_tensor(col[key], sizes[key], rec, device))
+        header["columns"].append({k: col[k] for k in ("name", "format", "nullable", "null_count", "offset")} |
+                                 {"sizes": sizes, "data_base": col.get("data_base", 0)})
+    return header, tensors
+
+
+def tensors_to_device_record(header, tensors, ctx):
+    """Inverse of `device_record_to_tensors`: wraps the received tensors (kept alive by the batch) as a DeviceRecordBatch."""
+    from ..record_utils import DeviceRecordBatch
+    cols, k = [], 0
+    for c in header["columns"]:
+        d = {key: c[key] for key in ("name", "format", "nullable", "null_count", "offset")}
+        for key in ("validity", "values", "data"):
+            if c["sizes"][key]:
+                d[key] = tensors[k].data_ptr() - (c.get("data_base", 0) if key == "data" else 0)
+                k += 1
+        if c["format"] == "u" and not c["sizes"]["data"]:
+            d["data"] = 0
+        if not c["sizes"]["validity"]:
+            d["null_count"] = 0
+        cols.append(d)
+    return DeviceRecordBatch.from_device_buffers(cols, header["num_rows"], ctx, keepalive=list(tensors))
+
+
+def send_device_record(rec, record_id: int, dst: int, table_aliases=None) -> None:
+    """Point-to-point transfer of a batch that lives in HBM to the GPU of rank `dst` (backend "nccl" = RCCL)."""
+    import torch
+    import torch.distributed as dist
+    header, tensors = device_record_to_tensors(rec)
+    header["record_id"] = record_id
+    header["table_aliases"] = table_aliases
+    device = tensors[0].device if tensors else torch.device("cuda", rec.ctx.device_id)
+    blob = torch.frombuffer(bytearray(json.dumps(header).encode()), dtype=torch.uint8).to(device)
+    dist.send(torch.tensor([blob.numel()], dtype=torch.int64, device=device), dst)
+    dist.send(blob, dst)
+    for t in tensors:
+        dist.send(t, dst)
+
+
+def recv_device_record(src: int, ctx):
+    """-> (record_id, DeviceRecordBatch, table_aliases); the buffers land in this rank's HBM and stay there."""
+    import torch
+    import torch.distributed as dist
+    device = torch.device("cuda", ctx.device_id)
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(n, src)
+    blob = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    dist.recv(blob, src)
+    header = json.loads(blob.cpu().numpy().tobytes().decode())
+    tensors = []
+    for c in header["columns"]:
+        for key in ("validity", "values", "data"):
+            if c["sizes"][key]:
+                t = torch.empty(c["sizes"][key] + 16, dtype=torch.uint8, device=device)[: c["sizes"][key]]
+                dist.recv(t, src)
+                tensors.append(t)
+    return header["record_id"], tensors_to_device_record(header, tensors, ctx), header.get("table_aliases")

@@ -176,7 +176,7 @@ class FilterTask:
 def _schema_of(rec):
     if hasattr(rec, "schema"):
         return rec.schema
-    return tuple(rec.column_names())
+    return tuple(zip(rec.column_names, rec.column_formats))
 
 
 class FilterTaskBuilder(TaskBuilder):

@@ -150,6 +150,47 @@ class DeviceRecordBatch:
     def column_names(self) -> List[str]:
         return [self._cb.schema.children[i].contents.name.decode() for i in range(self.num_columns)]
 
+    @property
+    def column_formats(self) -> List[str]:
+        """Arrow C format string of every column ("i", "f", "u", ...)."""
+        return [self._cb.schema.children[i].contents.format.decode() for i in range(self.num_columns)]
+
+    def describe_columns(self) -> List[dict]:
+        """name / format / nullable / null_count / offset / buffer addresses of every column -- what
+        `from_device_buffers` takes, e.g. to hand the buffers to RCCL without a copy."""
+        out = []
+        for i in range(self.num_columns):
+            sch = self._cb.schema.children[i].contents
+            arr = self._cb.array.array.children[i].contents
+            bufs = [arr.buffers[k] or 0 for k in range(arr.n_buffers)]
+            out.append({"name": sch.name.decode(), "format": sch.format.decode(), "nullable": bool(sch.flags & 2),
+                        "null_count": int(arr.null_count), "offset": int(arr.offset), "length": int(arr.length),
+                        "validity": bufs[0] if len(bufs) > 0 else 0, "values": bufs[1] if len(bufs) > 1 else 0,
+                        "data": bufs[2] if len(bufs) > 2 else 0})
+        return out
+
+    @staticmethod
+    def from_device_buffers(columns: Sequence[dict], num_rows: int, ctx: Optional[Context] = None,
+                            keepalive=None) -> "DeviceRecordBatch":
+        """Wrap caller-owned HBM buffers without copying; `columns` as returned by `describe_columns`
+        (validity / data optional)."""
+        ctx = ctx or default_context()
+        descs = (L.ColumnDesc * max(1, len(columns)))()
+        for i, col in enumerate(columns):
+            descs[i].name = col["name"].encode()
+            descs[i].format = col["format"].encode()
+            descs[i].nullable = 1 if col.get("nullable") else 0
+            descs[i].null_count = col.get("null_count", 0)
+            descs[i].offset = col.get("offset", 0)
+            descs[i].validity = col.get("validity") or None
+            descs[i].values = col.get("values") or None
+            descs[i].data = col.get("data") or None
+        out = _CBatch()
+        rc = L.lib().chq_wrap_columns(ctx.handle, descs, len(columns), num_rows, L.ARROW_DEVICE_ROCM, C.byref(out.array), C.byref(out.schema))
+        if rc:
+            raise ChqError(rc, ctx.last_error())
+        return DeviceRecordBatch(ctx, out, keepalive)
+
     def column_buffer_address(self, i: int, buffer: int = 1) -> int:
         """Device address of buffer `buffer` (0 validity, 1 values/offsets, 2 data) of column i."""
         return self._cb.array.array.children[i].contents.buffers[buffer] or 0
