@@ -115,6 +115,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
     else if (k == "split_rows") ctx->c.opt_split_rows = value;
     else if (k == "group_mode") ctx->c.opt_group_mode = value;
+    else if (k == "group_chunk_bytes") { if (value < 1 || value > (1ll << 30)) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "group_chunk_bytes must be 1..2^30"}; ctx->c.opt_group_chunk_bytes = value; }
     else if (k == "trim_pool") { DevicePool::instance().trim(); HostPool::instance().trim(); }
     else if (k == "host_pool_bytes") HostPool::instance().set_limit((size_t)(value < 0 ? 0 : value));
     else throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "unknown option: " + k};

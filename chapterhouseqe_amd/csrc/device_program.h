@@ -185,6 +185,16 @@ struct BitCompactParams {   // bool values / validity bitmaps
   u64* zero_count;     // optional: counts selected rows whose bit is 0 (null count)
 };
 
+struct SplitBoundsParams {   // split_bounds_kernel: out[i] = number of selected rows before input row starts[i]
+  int64_t nrows;
+  int64_t n;
+  const int64_t* starts;
+  const u64* sel_mask;
+  const u64* grp_base;
+  const u64* total;
+  u64* out;
+};
+
 struct GatherParams {      // gather_i32_kernel: dst[i] = *src[i]  (batches tiny device->host read-backs into one copy)
   const int32_t* src[16];
   int32_t* dst;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 
 namespace chq {
@@ -494,7 +495,7 @@ Column empty_like(const Column& c) {
 // =================================================================================================
 // filter_record
 // =================================================================================================
-Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr) {
+Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr, SplitRequest* split) {
   const int64_t nrows = rec.nrows;
   TypedExpr te = typed(ctx, rec, pcols, expr);
   const Node& root = te.at(te.root);
@@ -546,7 +547,8 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     else fixed_cols.push_back((int)i);
     if (c.validity && c.null_count != 0) nullable_cols.push_back((int)i);
   }
-  const bool need_followup = !bool_cols.empty() || !utf8_cols.empty() || !nullable_cols.empty() || (int)fixed_cols.size() > MAX_OUT;
+  const bool need_followup = !bool_cols.empty() || !utf8_cols.empty() || !nullable_cols.empty() || (int)fixed_cols.size() > MAX_OUT ||
+                             (split && !split->starts.empty());
   const int64_t ngroups = (mask_len + 63) / 64;
   BufferPtr sel_mask, grp_base;
   if (need_followup) {
@@ -630,6 +632,19 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   } while (next_fixed < fixed_cols.size());
 
   Scratch* hs = (Scratch*)ctx.pinned;
+  BufferPtr split_dev;
+  if (split && !split->starts.empty()) {   // output position of every concatenated input batch
+    const size_t n = split->starts.size();
+    split_dev = make_device_buffer(n * 16 + 16, ctx.device);
+    check_hip(hipMemcpyAsync(split_dev->ptr, split->starts.data(), n * 8, hipMemcpyHostToDevice, ctx.stream), "upload split rows");
+    SplitBoundsParams sp{};
+    sp.nrows = mask_len; sp.n = (int64_t)n; sp.starts = (const int64_t*)split_dev->ptr;
+    sp.sel_mask = (const u64*)sel_mask->ptr; sp.grp_base = (const u64*)grp_base->ptr; sp.total = &ds->total;
+    sp.out = (u64*)((uint8_t*)split_dev->ptr + n * 8);
+    check_hip(launch_split_bounds(sp, ctx.stream), "launch split_bounds_kernel");
+    split->bounds.assign(n, 0);
+    check_hip(hipMemcpyAsync(split->bounds.data(), sp.out, n * 8, hipMemcpyDeviceToHost, ctx.stream), "read back split bounds");
+  }
   if (utf8_cols.size() > 8) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 8 Utf8 columns in one batch"};
   if (!utf8_cols.empty()) {   // input byte span of every Utf8 column (= capacity of its output) rides on the same read-back
     GatherParams gp{};
@@ -738,6 +753,125 @@ void add_stats(chq_call_stats& acc, const chq_call_stats& s) {
   acc.rows_in += s.rows_in; acc.rows_out += s.rows_out; acc.tiles += s.tiles; acc.launches += s.launches;
   acc.bytes_read_alg += s.bytes_read_alg; acc.bytes_written_alg += s.bytes_written_alg; acc.kernel_ns += s.kernel_ns;
 }
+// f(begin, end) over [0, n) on a few host threads when there is enough to copy (one thread moves ~10 GB/s, the PCIe
+// link 55 GB/s: packing a group single-threaded would be the slowest step of a host-resident call)
+template <class F>
+void parallel_ranges(size_t n, size_t bytes, F&& f) {
+  unsigned T = bytes < ((size_t)8 << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (T > n) T = (unsigned)n;
+  if (T <= 1) { f((size_t)0, n); return; }
+  const size_t per = (n + T - 1) / T;
+  std::vector<std::thread> ts;
+  for (unsigned t = 1; t < T; ++t) ts.emplace_back([&f, t, per, n] { f(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+  f((size_t)0, std::min(n, per));
+  for (auto& th : ts) th.join();
+}
+
+// ---- host-side concatenation of a group (general column kinds) -----------------------------------------------
+// append n bits of src starting at bit src_bit (src == nullptr: ones) to dst at bit dst_bit; dst is zero-filled and has
+// 8 spare bytes behind its last bit
+void append_bits(uint8_t* dst, int64_t dst_bit, const uint8_t* src, int64_t src_bit, int64_t n) {
+  while (n > 0) {
+    const int k = (int)std::min<int64_t>(n, 56);
+    uint64_t v;
+    if (src) {
+      const int sh = (int)(src_bit & 7);
+      const int nbytes = (sh + k + 7) / 8;
+      uint64_t raw = 0;
+      memcpy(&raw, src + (src_bit >> 3), (size_t)nbytes);
+      v = (raw >> sh) & ((1ULL << k) - 1ULL);
+    } else {
+      v = (1ULL << k) - 1ULL;
+    }
+    const int dsh = (int)(dst_bit & 7);
+    uint64_t cur;
+    uint8_t* dp = dst + (dst_bit >> 3);
+    memcpy(&cur, dp, 8);
+    cur |= v << dsh;                       // k + dsh <= 63
+    memcpy(dp, &cur, 8);
+    dst_bit += k; src_bit += k; n -= k;
+  }
+}
+
+// one host batch holding the rows of recs[b0, b1) back to back (buffers from the recycling host pool)
+Batch concat_host_batches(const std::vector<Batch>& recs, size_t b0, size_t b1) {
+  Batch cat;
+  cat.on_device = false; cat.device_id = -1;
+  int64_t total = 0;
+  for (size_t b = b0; b < b1; ++b) total += recs[b].nrows;
+  cat.nrows = total;
+  const size_t ncols = recs[b0].cols.size();
+  for (size_t i = 0; i < ncols; ++i) {
+    const Column& c0 = recs[b0].cols[i];
+    Column o = empty_like(c0);
+    o.length = total;
+    bool any_nulls = false;
+    for (size_t b = b0; b < b1; ++b) { const Column& c = recs[b].cols[i]; any_nulls |= c.validity && c.null_count != 0; }
+    if (any_nulls) {
+      auto vb = make_host_buffer((size_t)(total + 7) / 8 + 16);
+      memset(vb->ptr, 0, (size_t)(total + 7) / 8 + 16);
+      int64_t at = 0, nulls = 0;
+      for (size_t b = b0; b < b1; ++b) {
+        const Column& c = recs[b].cols[i];
+        const bool has = c.validity && c.null_count != 0;
+        append_bits((uint8_t*)vb->ptr, at, has ? c.validity : nullptr, c.offset, c.length);
+        if (has) nulls += c.null_count > 0 ? c.null_count : count_nulls_host(c.validity, c.offset, c.length);
+        at += c.length;
+      }
+      o.validity = (const uint8_t*)vb->ptr; o.null_count = nulls; o.owned.push_back(vb);
+    }
+    if (c0.type == T_BOOL) {
+      auto vb = make_host_buffer((size_t)(total + 7) / 8 + 16);
+      memset(vb->ptr, 0, (size_t)(total + 7) / 8 + 16);
+      int64_t at = 0;
+      for (size_t b = b0; b < b1; ++b) { const Column& c = recs[b].cols[i]; append_bits((uint8_t*)vb->ptr, at, c.values, c.offset, c.length); at += c.length; }
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    } else if (c0.type == T_UTF8) {
+      const size_t n = b1 - b0;
+      std::vector<int64_t> row_at(n + 1, 0), byte_at(n + 1, 0);
+      for (size_t k = 0; k < n; ++k) {
+        const Column& c = recs[b0 + k].cols[i];
+        int64_t nbytes = 0;
+        if (c.values && c.length) { const int32_t* offs = (const int32_t*)c.values + c.offset; nbytes = (int64_t)offs[c.length] - offs[0]; }
+        row_at[k + 1] = row_at[k] + c.length; byte_at[k + 1] = byte_at[k] + nbytes;
+      }
+      auto ob = make_host_buffer((size_t)(total + 1) * 4 + 16);
+      auto db = make_host_buffer((size_t)byte_at[n] + 16);
+      int32_t* oo = (int32_t*)ob->ptr;
+      oo[0] = 0;
+      parallel_ranges(n, (size_t)byte_at[n] + (size_t)total * 4, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+          const Column& c = recs[b0 + k].cols[i];
+          if (!c.values || !c.length) continue;
+          const int32_t* offs = (const int32_t*)c.values + c.offset;
+          const int32_t first = offs[0];
+          const int64_t nbytes = byte_at[k + 1] - byte_at[k];
+          if (nbytes) memcpy((uint8_t*)db->ptr + byte_at[k], c.data + first, (size_t)nbytes);
+          const int32_t shift = (int32_t)(byte_at[k] - first);
+          int32_t* dst = oo + row_at[k];
+          for (int64_t r = 1; r <= c.length; ++r) dst[r] = offs[r] + shift;
+        }
+      });
+      o.values = (const uint8_t*)ob->ptr; o.owned.push_back(ob);
+      o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
+    } else {
+      const size_t n = b1 - b0;
+      std::vector<int64_t> row_at(n + 1, 0);
+      for (size_t k = 0; k < n; ++k) row_at[k + 1] = row_at[k] + recs[b0 + k].cols[i].length;
+      auto vb = make_host_buffer((size_t)total * c0.width + 16);
+      parallel_ranges(n, (size_t)total * c0.width, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+          const Column& c = recs[b0 + k].cols[i];
+          if (c.length) memcpy((uint8_t*)vb->ptr + row_at[k] * c.width, c.values0(), (size_t)c.length * c.width);
+        }
+      });
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    }
+    cat.cols.push_back(std::move(o));
+  }
+  return cat;
+}
+
 void ensure_pinned_table(Context& ctx, size_t bytes) {
   if (ctx.pinned_tbl_bytes >= bytes) return;
   if (ctx.pinned_tbl) (void)hipHostFree(ctx.pinned_tbl);
@@ -765,9 +899,92 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   };
   if (nb < 2) return per_batch_loop();
 
+  // ---- host batches with Utf8 / Boolean / nullable columns: concatenate on the host while staging, filter the one
+  // big batch (every column kind is supported there), copy the result back once and slice it per input batch at the
+  // positions the device reports (split_bounds_kernel).  Chunks keep every Utf8 column below 1 GiB of bytes.
+  auto host_concat_path = [&]() -> std::vector<Batch> {
+    const size_t nc = recs[0].cols.size();
+    std::vector<size_t> cuts{0};
+    {
+      std::vector<int64_t> bytes(nc, 0);
+      int64_t rows = 0;
+      for (size_t b = 0; b < nb; ++b) {
+        bool over = rows + recs[b].nrows > (1ll << 30);
+        const int64_t limit = ctx.opt_group_chunk_bytes;
+        std::vector<int64_t> add(nc, 0);
+        for (size_t i = 0; i < nc; ++i) {
+          const Column& c = recs[b].cols[i];
+          if (c.type == T_UTF8 && c.values && c.length) { const int32_t* o = (const int32_t*)c.values + c.offset; add[i] = (int64_t)o[c.length] - o[0]; }
+          over |= bytes[i] + add[i] > limit;
+        }
+        if (over && b > cuts.back()) { cuts.push_back(b); std::fill(bytes.begin(), bytes.end(), 0); rows = 0; }
+        for (size_t i = 0; i < nc; ++i) bytes[i] += add[i];
+        rows += recs[b].nrows;
+      }
+      cuts.push_back(nb);
+    }
+    std::vector<Batch> outs;
+    outs.reserve(nb);
+    chq_call_stats acc{};
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+      const size_t b0 = cuts[k], b1 = cuts[k + 1];
+      Batch cat = concat_host_batches(recs, b0, b1);
+      SplitRequest split;
+      int64_t at = 0;
+      for (size_t b = b0; b < b1; ++b) { split.starts.push_back(at); at += recs[b].nrows; }
+      split.starts.push_back(at);
+      Batch dev = to_device(ctx, cat);
+      Batch res = to_host(ctx, filter_record(ctx, dev, plan_columns(dev, aliases), expr, &split));
+      add_stats(acc, ctx.stats);
+      for (size_t b = b0; b < b1; ++b) {
+        const int64_t begin = split.bounds[b - b0], end = split.bounds[b - b0 + 1];
+        Batch o;
+        o.on_device = false; o.device_id = -1; o.nrows = end - begin;
+        for (const Column& c : res.cols) {
+          Column sc = c;   // shares the result buffers
+          sc.offset = c.offset + begin; sc.length = end - begin;
+          if (sc.validity) {
+            sc.null_count = count_nulls_host(sc.validity, sc.offset, sc.length);
+            if (sc.null_count == 0) sc.validity = nullptr;   // arrow drops an all-valid null buffer
+          } else sc.null_count = 0;
+          o.cols.push_back(std::move(sc));
+        }
+        outs.push_back(std::move(o));
+      }
+    }
+    ctx.stats = acc;
+    return outs;
+  };
+
   // ---- eligibility -----------------------------------------------------------------------------------
   const size_t ncols = recs[0].cols.size();
-  if (ncols == 0 || (int)ncols > MAX_OUT) return per_batch_loop();
+  if (ncols == 0) return per_batch_loop();
+  bool plain = (int)ncols <= MAX_OUT, same_schema = true, all_host = !recs[0].on_device;
+  for (const Batch& r : recs) {
+    if (r.cols.size() != ncols || r.nrows < 2) return per_batch_loop();
+    all_host &= !r.on_device;
+    for (size_t i = 0; i < ncols; ++i) {
+      const Column& c = r.cols[i];
+      same_schema &= c.type == recs[0].cols[i].type && c.width == recs[0].cols[i].width && c.format == recs[0].cols[i].format;
+      plain &= c.type != T_BOOL && c.type != T_UTF8 && !(c.validity && c.null_count != 0 && (r.on_device || c.null_count > 0 ||
+               count_nulls_host(c.validity, c.offset, c.length) != 0));
+    }
+  }
+  if (!same_schema) return per_batch_loop();
+  if (!plain) {
+    if (!all_host || out_on_device) return per_batch_loop();
+    try {
+      TypedExpr probe = type_expr(expr, plan_columns(recs[0], aliases), recs[0].nrows, ctx.opt_enable_minus);
+      if (probe.pending_code || probe.at(probe.root).type != T_BOOL || probe.at(probe.root).len1) return per_batch_loop();
+    } catch (const ChqError&) {
+      return per_batch_loop();   // reports the first batch's (static) error
+    }
+    try {
+      return host_concat_path();
+    } catch (const ChqError&) {
+      return per_batch_loop();   // a data-dependent error: the loop reports the earliest failing batch's
+    }
+  }
   int64_t total_rows = 0, max_rows = 0;
   const bool host_in = !recs[0].on_device;
   for (const Batch& r : recs) {
@@ -803,13 +1020,12 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
       const int64_t w = recs[0].cols[i].width;
       auto pack = make_host_buffer((size_t)(total_rows * w) + 16);   // recycled block: no page faults
       auto db = make_device_buffer((size_t)(total_rows * w) + 16, ctx.device);
-      int64_t at = 0;
-      for (size_t b = 0; b < nb; ++b) {
-        memcpy((uint8_t*)pack->ptr + at, recs[b].cols[i].values0(), (size_t)(recs[b].nrows * w));
-        in_ptr[b][i] = (const uint8_t*)db->ptr + at;
-        at += recs[b].nrows * w;
-      }
-      check_hip(hipMemcpyAsync(db->ptr, pack->ptr, (size_t)at, hipMemcpyHostToDevice, ctx.stream), "upload packed column");
+      std::vector<int64_t> at(nb + 1, 0);
+      for (size_t b = 0; b < nb; ++b) { at[b + 1] = at[b] + recs[b].nrows * w; in_ptr[b][i] = (const uint8_t*)db->ptr + at[b]; }
+      parallel_ranges(nb, (size_t)at[nb], [&](size_t k0, size_t k1) {
+        for (size_t b = k0; b < k1; ++b) memcpy((uint8_t*)pack->ptr + at[b], recs[b].cols[i].values0(), (size_t)(recs[b].nrows * w));
+      });
+      check_hip(hipMemcpyAsync(db->ptr, pack->ptr, (size_t)at[nb], hipMemcpyHostToDevice, ctx.stream), "upload packed column");
       staged.push_back(db); staged.push_back(pack);
     }
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");

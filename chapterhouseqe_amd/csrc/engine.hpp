@@ -23,6 +23,7 @@ hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t s
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);
+hipError_t launch_split_bounds(const SplitBoundsParams& p, hipStream_t stream);
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
 
@@ -119,6 +120,7 @@ struct Context {
   int64_t opt_fuse = 1;             // chq_filter_project_record's single-pass kernel: 0 never, 1 when it moves clearly fewer bytes, 2 whenever possible
   int64_t opt_grid_per_cu = 0;
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
+  int64_t opt_group_chunk_bytes = 1ll << 30;   // host-concatenated groups: Utf8 bytes per column and chunk (int32 offsets)
   int64_t opt_group_mode = 0;       // batch-group launch: 0 auto, 1 force per-tile table, 2 force wave-granular packing
   int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -144,7 +146,11 @@ Batch to_device(Context& ctx, const Batch& b);   // stage host batch into HBM (n
 Batch to_host(Context& ctx, const Batch& b);
 
 // the record-level operations (throw ChqError)
-Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr);
+// `split`: optional input-row positions (ascending); on return bounds[i] = selected rows before starts[i], i.e. where the
+// output of a batch that was concatenated into `rec_dev` at row starts[i] begins
+struct SplitRequest { std::vector<int64_t> starts; std::vector<int64_t> bounds; };
+Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr,
+                    SplitRequest* split = nullptr);
 // one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
                                   const Expr& expr, bool out_on_device);

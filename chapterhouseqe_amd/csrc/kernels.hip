@@ -1444,6 +1444,20 @@ __global__ void gather_i32_kernel(const GatherParams p) {
   const int i = threadIdx.x;
   if (i < p.n) p.dst[i] = *p.src[i];
 }
+// out[i] = selected rows among input rows [0, starts[i]): where the output of a batch concatenated at row starts[i] begins
+__global__ void split_bounds_kernel(const SplitBoundsParams p) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  const int64_t r = p.starts[i];
+  if (r >= p.nrows) { p.out[i] = *p.total; return; }
+  const int64_t g = r >> 6;
+  p.out[i] = p.grp_base[g] + (u64)__popcll(p.sel_mask[g] & ((1ULL << (r & 63)) - 1ULL));
+}
+hipError_t launch_split_bounds(const SplitBoundsParams& p, hipStream_t stream) {
+  if (p.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split_bounds_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
 __global__ void gather_status_kernel(const GatherStatusParams p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < p.n) p.dst[i] = ST_VAL(p.status[p.idx[i]]);

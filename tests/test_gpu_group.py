@@ -118,31 +118,57 @@ def test_group_result_outlives_its_siblings(ctx):
     del junk
 
 
+def mixed_batch(n, seed, nulls):
+    r = np.random.default_rng(seed)
+    m = (lambda p: (r.random(n) < p)) if nulls and n else (lambda p: None)
+    words = np.array(["", "a", "ab", "zeta", "a much longer string value that spans more than sixty-four bytes of utf8 text ..."])
+    return pa.RecordBatch.from_arrays(
+        [pa.array(r.integers(0, 100, n).astype(np.int32), mask=m(0.2)),
+         pa.array(words[r.integers(0, len(words), n)] if n else np.array([], dtype=object), type=pa.utf8(), mask=m(0.1)),
+         pa.array(r.integers(0, 2, n).astype(bool), mask=m(0.15)),
+         pa.array(r.random(n) * 10)], names=["a", "s", "f", "d"])
+
+
 @pytest.mark.parametrize("device", [True, False], ids=["device", "host"])
-def test_groups_outside_the_fast_path_take_the_loop(ctx, device):
-    """Utf8 / Boolean / nullable columns, 0- and 1-row batches, literal-only predicates: same results, batch by batch"""
-    rng = np.random.default_rng(5)
-
-    def mixed(n, seed, nulls):
-        r = np.random.default_rng(seed)
-        m = (r.random(n) < 0.2) if nulls and n else None
-        return pa.RecordBatch.from_arrays(
-            [pa.array(r.integers(0, 100, n).astype(np.int32), mask=m), pa.array(["s%d" % v for v in r.integers(0, 9, n)], type=pa.utf8()),
-             pa.array(r.integers(0, 2, n).astype(bool))], names=["a", "s", "f"])
-
+def test_groups_outside_the_one_launch_path(ctx, device):
+    """Utf8 / Boolean / nullable columns, 0- and 1-row batches, literal-only predicates: same results.  Device-resident
+    groups run batch by batch inside the call; host groups are concatenated while staging (next test)."""
     groups = [
-        ([mixed(n, 40 + n, False) for n in (100, 3000, 17)], "a > 50 and s <> 's3'"),
-        ([mixed(n, 50 + n, True) for n in (100, 3000, 17)], "a > 50 or f"),
+        ([mixed_batch(n, 40 + n, False) for n in (100, 3000, 17)], "a > 50 and s <> 'ab'"),
+        ([mixed_batch(n, 50 + n, True) for n in (100, 3000, 17)], "a > 50 or f"),
         ([fixed_batch(n, 60 + n) for n in (100, 0, 1, 5000)], "value2 > 10.0"),
         ([fixed_batch(n, 70 + n) for n in (100, 200)], "1 = 1"),
     ]
-    del rng
     for recs, sql in groups:
-        st = check_group(ctx, recs, sql, device)
-        assert st["launches"] >= len([r for r in recs if r.num_rows > 0])
+        check_group(ctx, recs, sql, device)
 
 
-def test_a_single_null_moves_the_whole_group_to_the_loop(ctx):
+@pytest.mark.parametrize("chunk_bytes", [1 << 30, 20_000], ids=["one-chunk", "many-chunks"])
+def test_host_groups_with_strings_booleans_and_nulls_are_concatenated(chunk_bytes):
+    """the reference's sample tables carry a Utf8 column: 150 small host batches (some sliced, so every buffer carries
+    an Arrow offset) are staged as ONE batch, filtered by a handful of launches and sliced per record id"""
+    c = chq.Context(0)
+    c.set_option("group_chunk_bytes", chunk_bytes)
+    sizes = [int(x) for x in np.random.default_rng(1).integers(2, 900, 150)]
+    recs = []
+    for i, n in enumerate(sizes):
+        b = mixed_batch(n + 11, 2000 + i, nulls=(i % 3 != 0))
+        recs.append(b.slice(5 + i % 7, n) if i % 2 else b.slice(0, n))
+    for sql in ["a > 50 and s <> 'ab'", "f or d * 2.0 > 15.0", "s >= 'ab'", "a % 7 = 0", "a = a", "d < 0.0"]:
+        st = check_group(c, recs, sql, device=False)
+        if chunk_bytes == 1 << 30:
+            assert st["launches"] <= 12, (sql, st)          # not 150 x (main + follow-up kernels)
+    # an error in one batch: the whole call fails with that batch's error, nothing is returned
+    bad = list(recs)
+    bad[77] = pa.RecordBatch.from_arrays([pa.array(np.full(20, 2**31 - 1, dtype=np.int32)), pa.array(["x"] * 20, type=pa.utf8()),
+                                          pa.array([True] * 20), pa.array(np.zeros(20))], names=["a", "s", "f", "d"])
+    with pytest.raises(chq.ChqError) as ei:
+        chq.filter_records(bad, empty_aliases(bad[0]), parse_expr("a + 1 > 0"), ctx=c)
+    assert ei.value.code == 20
+    c.close()
+
+
+def test_a_single_null_leaves_the_one_launch_path(ctx):
     recs = [fixed_batch(4000, 80 + i, with_wide=False) for i in range(4)]
     v = recs[2].column(1).to_numpy().copy()
     mask = np.zeros(len(v), dtype=bool)
