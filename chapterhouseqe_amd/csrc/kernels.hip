@@ -340,10 +340,30 @@ struct Interp {
   }
 
   // ---- arithmetic: arrow-arith numeric::{add,sub,mul,div,rem}; checked for integers ----------------
-  __device__ __forceinline__ void arith(int op, int t, bool rev, const uint32_t (&bl_)[R], const uint32_t (&bh_)[RH], u64* err, uint32_t ref_order) {
+  __device__ __forceinline__ void arith(int op, int t, bool rev, bool bconst, const uint32_t (&bl_)[R], const uint32_t (&bh_)[RH], u64* err, uint32_t ref_order) {
 #define bl(j) bl_[j]
 #define bh(j) bh_[j]
     const int cls = vclass(t);
+    // x / 2^k and x % 2^k with a literal divisor (`id % 2 = 0` is in the reference's sample queries): shifts and masks
+    // instead of the ~40-instruction software division; cannot fail (divisor > 0), truncates toward zero like arrow's
+    // div / rem (sign of the dividend)
+    if ((op == OP_DIV || op == OP_REM) && bconst && !rev && (cls == C_I32 || cls == C_U32)) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl(0));
+      if (d != 0 && d <= 0x40000000u && (d & (d - 1)) == 0) {
+        const int k = __builtin_ctz(d);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (cls == C_I32) {
+            const int32_t x = (int32_t)lo[j];
+            const int32_t q = (x + ((x >> 31) & (int32_t)(d - 1))) >> k;
+            lo[j] = op == OP_DIV ? (uint32_t)q : (uint32_t)(x - (int32_t)((uint32_t)q << k));
+          } else {
+            lo[j] = op == OP_DIV ? lo[j] >> k : lo[j] & (d - 1);
+          }
+        }
+        return;
+      }
+    }
     int errj = -1; uint32_t errc = 0;   // first offending slot of this lane (= its smallest row)
 #define BAD(code) do { if (live && errj < 0) { errj = j; errc = (code); } } while (0)
     if (cls == C_I32) {
@@ -619,7 +639,7 @@ struct Interp {
           break;
         case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_REM:
           validv &= bv;
-          arith(in.op, in.type, rev, bl, bh, err, in.ref_order);
+          arith(in.op, in.type, rev, bconst, bl, bh, err, in.ref_order);
           acc_type = in.type;
           break;
         case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE:
@@ -1201,18 +1221,19 @@ __global__ __launch_bounds__(BLOCK) void utf8_filter_kernel(const Utf8Params p) 
     const int64_t tile = uniform64(s_tile);
     if (tile >= ntiles) break;
     const int64_t w0 = tile * TILE + (int64_t)wv * 64 * G;
-    int32_t src[G]; uint32_t len[G]; u64 msk[G];
+    int32_t src[G]; uint32_t len[G]; u64 msk[G]; u64 gbase[G];
     u64 bytes = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int64_t r0 = w0 + 64 * g;
       const u64 act = active_mask(r0, p.nrows);
       msk[g] = act ? (p.sel_mask[r0 >> 6] & act) : 0ULL;
-      src[g] = 0; len[g] = 0;
+      src[g] = 0; len[g] = 0; gbase[g] = 0;
       if (msk[g]) {   // uniform
         const int64_t last = p.nrows - r0 < 64 ? p.nrows - r0 : 64;             // offsets r0 .. r0+last are valid
         const int32_t o = p.in_offsets[r0 + (lane < last ? lane : last)];
         const int32_t oend = p.in_offsets[r0 + last];                            // broadcast load
+        gbase[g] = p.grp_base[r0 >> 6];                                          // needed in pass 2: fetch it now
         int32_t nxt = __shfl_down(o, 1, 64);
         if (lane + 1 >= last) nxt = oend;
         src[g] = o;
@@ -1241,42 +1262,69 @@ __global__ __launch_bounds__(BLOCK) void utf8_filter_kernel(const Utf8Params p) 
     u64 boff = s_base_bytes;
     for (int w = 0; w < wv; ++w) boff += s_wave_bytes[w];
     boff = (u64)uniform64((int64_t)boff);
-#pragma unroll 1
+    // ---- pass 2a: new offsets; every group's byte base and every row's position inside it ---------------------
+    uint32_t dsto[G]; u64 gboff[G]; uint32_t longg = 0;   // bit g of longg: the group takes the long-string path
+#pragma unroll
     for (int g = 0; g < G; ++g) {
+      dsto[g] = 0; gboff[g] = boff;
       if (!msk[g]) continue;
       const bool sel = (msk[g] >> lane) & 1;
       uint32_t inc = len[g];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-      const uint32_t dsto = inc - len[g];                       // byte position of this row inside the group's output
+      dsto[g] = inc - len[g];                                     // byte position of this row inside the group's output
       const uint32_t group_bytes = __shfl(inc, 63, 64);
-      const int cnt = __popcll(msk[g]);
-      if (sel) p.out_offsets[p.grp_base[(w0 >> 6) + g] + lane_rank(msk[g])] = (int32_t)(boff + dsto);
-      uint8_t* gdst = p.out_data + boff;
-      if (group_bytes <= (uint32_t)cnt * 24u) {
-        if (sel) {   // short strings: one lane per row
-          const uint8_t* sp = p.in_data + src[g];
-          uint8_t* dp = gdst + dsto;
-          const int l = (int)len[g];
-          int b = 0;
-          for (; b + 4 <= l; b += 4) { uint32_t w; __builtin_memcpy(&w, sp + b, 4); __builtin_memcpy(dp + b, &w, 4); }
-          for (; b < l; ++b) dp[b] = sp[b];
-        }
-      } else {
-        // long strings: bring (src, len, dst) of the selected rows into rank order, half a wave per row
-        const unsigned dl = sel ? lane_rank(msk[g]) : 63u - lane_rank(~msk[g]);
-        const int rs = __builtin_amdgcn_ds_permute((int)(dl << 2), src[g]);
-        const int rl = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)len[g]);
-        const int rd = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)dsto);
-        const int half = lane >> 5, hl = lane & 31;
-        for (int k = 0; k < cnt; k += 2) {
-          const int r = k + half;
-          const int rr = r < cnt ? r : cnt - 1;
-          const int sr = __shfl(rs, rr, 64), lr = __shfl(rl, rr, 64), dr = __shfl(rd, rr, 64);
-          if (r < cnt) copy_row_chunks(p.in_data + sr, gdst + dr, lr, hl, 32);
+      if (sel) p.out_offsets[gbase[g] + lane_rank(msk[g])] = (int32_t)(boff + dsto[g]);
+      if (group_bytes > (uint32_t)__popcll(msk[g]) * 24u) longg |= 1u << g;
+      boff += group_bytes;
+    }
+    // ---- pass 2b: short strings, one lane per row.  The first 16 bytes of every selected row of ALL groups are
+    // loaded before anything is stored (8 x 4 loads in flight per lane instead of one dependent load/store pair at a
+    // time); whatever is longer than 16 bytes, and the 1-3 tail bytes, follow in a per-lane loop. --------------------
+    {
+      uint32_t w4[G][4];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint8_t* sp = p.in_data + src[g];
+        const bool shortg = msk[g] && !((longg >> g) & 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          w4[g][q] = 0;
+          if (shortg && (uint32_t)(4 * q + 4) <= len[g]) __builtin_memcpy(&w4[g][q], sp + 4 * q, 4);
         }
       }
-      boff += group_bytes;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const bool shortg = msk[g] && !((longg >> g) & 1);
+        if (!shortg) continue;
+        const uint8_t* sp = p.in_data + src[g];
+        uint8_t* dp = p.out_data + gboff[g] + dsto[g];
+        const int l = (int)len[g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (4 * q + 4 <= l) __builtin_memcpy(dp + 4 * q, &w4[g][q], 4);
+        int b = l < 16 ? (l & ~3) : 16;
+        for (; b + 4 <= l; b += 4) { uint32_t w; __builtin_memcpy(&w, sp + b, 4); __builtin_memcpy(dp + b, &w, 4); }
+        for (; b < l; ++b) dp[b] = sp[b];
+      }
+    }
+    // ---- pass 2c: long strings: (src, len, dst) of the selected rows in rank order, half a wave per row ------------
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      if (!((longg >> g) & 1)) continue;
+      const bool sel = (msk[g] >> lane) & 1;
+      const int cnt = __popcll(msk[g]);
+      uint8_t* gdst = p.out_data + gboff[g];
+      const unsigned dl = sel ? lane_rank(msk[g]) : 63u - lane_rank(~msk[g]);
+      const int rs = __builtin_amdgcn_ds_permute((int)(dl << 2), src[g]);
+      const int rl = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)len[g]);
+      const int rd = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)dsto[g]);
+      const int half = lane >> 5, hl = lane & 31;
+      for (int k = 0; k < cnt; k += 2) {
+        const int r = k + half;
+        const int rr = r < cnt ? r : cnt - 1;
+        const int sr = __shfl(rs, rr, 64), lr = __shfl(rl, rr, 64), dr = __shfl(rd, rr, 64);
+        if (r < cnt) copy_row_chunks(p.in_data + sr, gdst + dr, lr, hl, 32);
+      }
     }
     __syncthreads();
   }

@@ -306,3 +306,31 @@ def test_errors_leave_no_partial_output_and_context_stays_usable(ctx):
         chq.filter_record(rec, al, parse_expr("i32 / (small % 1) > 0"), ctx=ctx)
     assert ei.value.code == 21
     assert check_same(ctx, rec, al, "i32 > 0", "filter") == "ok"
+
+
+def test_power_of_two_literal_divisors(ctx):
+    """x / 2^k and x % 2^k with a literal divisor take a shift/mask path on the device: truncation toward zero and the
+    sign of the dividend must survive it, for every 32-bit-class integer type and the extremes"""
+    rng = np.random.default_rng(17)
+    n = 3000
+
+    def col(dt, lo, hi):
+        v = rng.integers(lo, hi, n, endpoint=True).astype(dt)
+        v[:6] = np.array([lo, hi, 0, 1, lo + 1, hi - 1]).astype(dt)
+        if lo < 0:
+            v[6] = -1
+        return pa.array(v)
+
+    rec = pa.RecordBatch.from_arrays(
+        [col(np.int8, -128, 127), col(np.int16, -32768, 32767), col(np.int32, -2**31, 2**31 - 1),
+         col(np.uint8, 0, 255), col(np.uint16, 0, 65535), col(np.uint32, 0, 2**32 - 1)],
+        names=["i8", "i16", "i32", "u8", "u16", "u32"])
+    al = empty_aliases(rec)
+    for c, divisors in [("i8", [1, 2, 64]), ("i16", [1, 2, 4096]), ("i32", [1, 2, 8, 65536, 1073741824]),
+                        ("u8", [1, 2, 128]), ("u16", [1, 2, 32768])]:   # (UInt32 has no common type with an Int32 literal)
+        for d in divisors:
+            for sql in [f"{c} / {d}", f"{c} % {d}", f"({c} % {d}) = 0", f"{c} / {d} * {d} + {c} % {d} = {c}"]:
+                assert check_same(ctx, rec, al, sql, "value") == "ok", sql
+    # not powers of two, reversed operands, zero: the general path (and its errors) as before
+    for sql, want in [("i32 % 3", "ok"), ("i32 / 7", "ok"), ("64 / u8", "error"), ("i32 % 0", "error"), ("u16 / 0", "error")]:
+        assert check_same(ctx, rec, al, sql, "value") == want, sql
