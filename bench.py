@@ -33,7 +33,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     ap.add_argument("--predicate", default=PREDICATE)
     ap.add_argument("--cpu-rows", type=int, default=1_000_000_000, help="rows of the same data timed on the CPU oracle")

@@ -111,7 +111,6 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
     else if (k == "stash") ctx->c.opt_stash = value != 0;
     else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }
-    else if (k == "debug") ctx->c.opt_debug = value;
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
     else if (k == "split_rows") ctx->c.opt_split_rows = value;
     else if (k == "group_mode") ctx->c.opt_group_mode = value;

@@ -120,7 +120,7 @@ struct FilterParams {
   int16_t n_out;
   int16_t stash_ref;      // program column-ref whose raw tile values stay in LDS between P and C (-1: none); when set,
                           // that column is outs[n_out - 1] and is copied from LDS instead of being fetched again
-  int32_t debug;          // experiments only: bit0 = no inter-tile dependency (base = tile * TILE), bit1 = skip last column
+  int32_t pad0;
   // Batch-group launch (chq_filter_records): many batches of one schema, one launch, one dense compaction.  Tiles never
   // straddle batches; row `tile` of this table (group_stride words) = { first row of the tile inside its batch, rows of
   // that batch, value pointers of the n_refs program inputs, input pointers of the n_out copied columns }.

@@ -603,7 +603,6 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       ++n;
     }
     p.n_out = (int16_t)n;
-    p.debug = (int32_t)ctx.opt_debug;
     if (first) check_hip(hipMemsetAsync(ds, 0, kHeader + (size_t)(ntiles + 1) * 8, ctx.stream), "memset scratch + status");
     else {
       check_hip(hipMemsetAsync(ds, 0, kPerPass, ctx.stream), "memset scratch");
@@ -1125,7 +1124,6 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
     p.outs[k].in = nullptr; p.outs[k].out = dense[launch_cols[k]]->ptr; p.outs[k].width = (uint32_t)recs[0].cols[launch_cols[k]].width;
   }
   p.n_out = (int16_t)nout;
-  p.debug = (int32_t)(ctx.opt_debug & ~1);
   p.group = (const u64*)d_tbl->ptr; p.group_stride = (int64_t)stride;
   p.group_wpb = (int32_t)wpb; p.group_nb = (int32_t)nb; p.group_batch_end = d_cnt;
   p.tile_begin = 0; p.tile_end = ntiles;

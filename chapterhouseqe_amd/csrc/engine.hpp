@@ -122,7 +122,6 @@ struct Context {
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
   int64_t opt_group_chunk_bytes = 1ll << 30;   // host-concatenated groups: Utf8 bytes per column and chunk (int32 offsets)
   int64_t opt_group_mode = 0;       // batch-group launch: 0 auto, 1 force per-tile table, 2 force wave-granular packing
-  int64_t opt_debug = 0;            // kernel experiments (never set in production paths)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // reusable device scratch
   BufferPtr small;          // [Scratch header (512 B)] [status words of the chained scan]: cleared by ONE memset per call

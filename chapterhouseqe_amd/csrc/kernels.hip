@@ -778,12 +778,11 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     const int64_t tile = uniform64(s_tile[buf]);
     if (wv == 0) {
       u64 excl = 0;
-      if (p.debug & 1) excl = (u64)(tile * TILE);
-      else if (tile > 0) {
+      if (tile > 0) {
         excl = lookback_exclusive(p.status, tile, 0, lane);
         if (lane == 0) st_store(&p.status[tile], ST_INC | (excl + s_tot[buf]));
       }
-      if (lane == 0) { s_base = excl; if (tile == last_tile) *p.total = (p.debug & 1) ? (u64)p.nrows : excl + s_tot[buf]; }
+      if (lane == 0) { s_base = excl; if (tile == last_tile) *p.total = excl + s_tot[buf]; }
     }
     __syncthreads();
     u64 off0 = s_base;
@@ -831,7 +830,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         run += __popcll(m);
       }
     }
-    const int ncopy = ((p.debug & 2) || p.stash_ref >= 0) ? p.n_out - 1 : p.n_out;   // the stashed column is outs[n_out-1]
+    const int ncopy = p.stash_ref >= 0 ? p.n_out - 1 : p.n_out;   // the stashed column is outs[n_out-1]
     auto copy_columns = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       for (int c = 0; c < ncopy; ++c) {
@@ -910,7 +909,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
       if (nact == 64 * R) copy_columns(std::true_type{});   // complete wave: unclamped, immediate-offset loads
       else copy_columns(std::false_type{});
     } else copy_columns(std::true_type{});
-    if (p.stash_ref >= 0 && !(p.debug & 2)) {   // the predicate column: values are still in LDS
+    if (p.stash_ref >= 0) {   // the predicate column: values are still in LDS
       const OutCol oc = p.outs[p.n_out - 1];
       const uint32_t* sv = s_stash[buf] + tid;
       unsigned run = 0;
@@ -926,17 +925,6 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     }
   };
 
-  if (p.debug & 8) {
-    // non-pipelined order: C(i) follows P(i) immediately, so the copy phase re-reads the predicate's input columns
-    // while they are still in L2 / Infinity Cache; the look-back wait is exposed instead
-    while (true) {
-      P(0);
-      if (s_tile[0] >= ntiles) break;
-      C(0);
-      __syncthreads();
-    }
-    return;
-  }
   P(0);
   int itn = 0;
   while (true) {
