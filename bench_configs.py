@@ -229,6 +229,17 @@ def main():
             t2 = time.perf_counter()
             ccall.append((t1 - t0) * 1e3); crel.append((t2 - t1) * 1e3)
         L.lib().chq_expr_free(ce)
+        # the coalesced form: ONE output batch (the kernel's dense buffers), nothing exported per input batch
+        coal = []
+        for it in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            big, rows_per = chq.filter_records_coalesced(grp, al, pred, ctx=ctx)
+            t1 = time.perf_counter()
+            assert big.num_rows == rows_out and rows_per == counts
+            big.release()
+            if it:
+                coal.append((t1 - t0) * 1e3)
         # the per-batch loop on a subset, same batches
         sub = min(nb, 2000)
         torch.cuda.synchronize()
@@ -243,6 +254,7 @@ def main():
              "group_kernel_frac_of_8TBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9 / HBM_PEAK,
              "rows_per_s_group_call": n / (wall[len(wall) // 2] * 1e-3),
              "c_call_ms": min(ccall), "rows_per_s_c_call": n / (min(ccall) * 1e-3), "python_release_ms": min(crel),
+             "coalesced_call_ms": min(coal), "rows_per_s_coalesced_call": n / (min(coal) * 1e-3),
              "per_batch_loop_us_per_batch": loop_s / sub * 1e6, "rows_per_s_per_batch_loop": sub * rows_per_batch / loop_s,
              "wrap_inputs_s": wrap_s, "note": note}
         results.append(r)

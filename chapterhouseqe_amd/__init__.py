@@ -6,9 +6,10 @@ the C ABI of include/chq.h, plus the host-side mirror of the reference's interfa
 """
 from . import sqlast, sqlparse  # noqa: F401
 from .record_utils import (ChqError, Context, DeviceRecordBatch, compute_value, default_context,  # noqa: F401
-                           filter_project_record, filter_record, filter_records, get_record_table_aliases,
+                           filter_project_record, filter_record, filter_records, filter_records_coalesced,
+                           get_record_table_aliases,
                            project_record, RecordGroup)
 
 __all__ = ["sqlast", "sqlparse", "ChqError", "Context", "DeviceRecordBatch", "compute_value", "default_context",
-           "filter_project_record", "filter_record", "filter_records", "get_record_table_aliases", "project_record",
+           "filter_project_record", "filter_record", "filter_records", "filter_records_coalesced", "get_record_table_aliases", "project_record",
            "RecordGroup"]

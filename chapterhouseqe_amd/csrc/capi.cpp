@@ -203,6 +203,28 @@ chq_status chq_filter_records(chq_ctx* ctx, int n_records, const ArrowDeviceArra
   });
 }
 
+chq_status chq_filter_records_coalesced(chq_ctx* ctx, int n_records, const ArrowDeviceArray* const* recs, const ArrowSchema* schema,
+                                        const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
+                                        ArrowDeviceArray* out, ArrowSchema* out_schema, int64_t* rows_per_record) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(expr, "expression"); require(out, "output array"); require(out_schema, "output schema");
+    if (n_records <= 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "at least one record batch is needed"};
+    require(recs, "record array");
+    if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    std::vector<Batch> in;
+    in.reserve((size_t)n_records);
+    for (int i = 0; i < n_records; ++i) { require(recs[i], "record"); in.push_back(import_batch(recs[i], schema)); }
+    std::vector<int64_t> rows;
+    Batch res = filter_records_coalesced(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &rows);
+    if (rows_per_record) for (int i = 0; i < n_records; ++i) rows_per_record[i] = rows[(size_t)i];
+    export_batch(std::move(res), out_device, out, out_schema);
+  });
+}
+
 chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n_fields, const ArrowDeviceArray* rec,
                               const ArrowSchema* schema, const chq_table_aliases* table_aliases, int out_device,
                               ArrowDeviceArray* out, ArrowSchema* out_schema) {

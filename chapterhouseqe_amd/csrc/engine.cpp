@@ -128,6 +128,18 @@ const void* Column::values0() const {
 
 static void parse_format(const char* f, DType* t, int* width) {
   *width = 0;
+  if (f && f[0] && !f[1]) {   // the primitive types are one character: no string object on the per-batch import path
+    switch (f[0]) {
+      case 'b': *t = T_BOOL; return;
+      case 'c': *t = T_I8; *width = 1; return;   case 'C': *t = T_U8; *width = 1; return;
+      case 's': *t = T_I16; *width = 2; return;  case 'S': *t = T_U16; *width = 2; return;
+      case 'i': *t = T_I32; *width = 4; return;  case 'I': *t = T_U32; *width = 4; return;
+      case 'l': *t = T_I64; *width = 8; return;  case 'L': *t = T_U64; *width = 8; return;
+      case 'e': *t = T_F16; *width = 2; return;  case 'f': *t = T_F32; *width = 4; return;
+      case 'g': *t = T_F64; *width = 8; return;  case 'u': *t = T_UTF8; return;
+      default: break;
+    }
+  }
   std::string s(f ? f : "");
   if (s == "b") { *t = T_BOOL; return; }
   if (s == "c") { *t = T_I8; *width = 1; return; }
@@ -156,7 +168,7 @@ static void parse_format(const char* f, DType* t, int* width) {
 
 Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema) {
   if (!rec || !schema || !schema->format) throw ChqError{CHQ_ERR_INVALID_HANDLE, "null record batch"};
-  if (std::string(schema->format) != "+s") throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "record batch must be a struct array"};
+  if (strcmp(schema->format, "+s") != 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "record batch must be a struct array"};
   const ArrowArray& a = rec->array;
   if (a.offset != 0) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "sliced struct arrays are not supported; slice the children"};
   if (a.n_children != schema->n_children) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "schema / array children mismatch"};
@@ -169,6 +181,7 @@ Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema) {
     default: throw ChqError{CHQ_ERR_NOT_SUPPORTED, "unsupported Arrow device type"};
   }
   if (b.on_device && rec->sync_event) check_hip(hipEventSynchronize(*(hipEvent_t*)rec->sync_event), "hipEventSynchronize(sync_event)");
+  b.cols.reserve((size_t)a.n_children);
   for (int64_t i = 0; i < a.n_children; ++i) {
     const ArrowArray* ca = a.children[i];
     const ArrowSchema* cs = schema->children[i];
@@ -881,8 +894,40 @@ void ensure_pinned_table(Context& ctx, size_t bytes) {
 }
 }  // namespace
 
+namespace {
+// `co` != nullptr asks for ONE output batch (all surviving rows, input order) + rows per input batch; the one-launch
+// path fills it directly and sets co->done, every other path returns per-batch outputs for the caller to join
+struct Coalesced { Batch out; std::vector<int64_t> rows; bool done = false; };
+std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
+                                       const Expr& expr, bool out_on_device, Coalesced* co);
+}  // namespace
+
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
                                   const Expr& expr, bool out_on_device) {
+  return filter_records_impl(ctx, recs, aliases, expr, out_on_device, nullptr);
+}
+
+Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
+                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record) {
+  if (recs.empty()) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "no record batches to coalesce"};
+  Coalesced co;
+  std::vector<Batch> outs = filter_records_impl(ctx, recs, aliases, expr, out_on_device, &co);
+  if (!co.done) {   // join the per-batch results on the host (general column kinds), then move them where they are wanted
+    const chq_call_stats st = ctx.stats;
+    std::vector<Batch> host;
+    for (Batch& o : outs) { co.rows.push_back(o.nrows); host.push_back(o.on_device ? to_host(ctx, o) : std::move(o)); }
+    Batch cat = concat_host_batches(host, 0, host.size());
+    co.out = out_on_device ? to_device(ctx, cat) : std::move(cat);
+    if (out_on_device) check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+    ctx.stats = st;
+  }
+  if (rows_per_record) *rows_per_record = co.rows;
+  return std::move(co.out);
+}
+
+namespace {
+std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
+                                       const Expr& expr, bool out_on_device, Coalesced* co) {
   const size_t nb = recs.size();
   auto per_batch_loop = [&]() {
     std::vector<Batch> outs;
@@ -1013,7 +1058,10 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   // ---- inputs: device pointers per batch and column ------------------------------------------------------
   // host batches are packed column-wise into one staging block per column and uploaded with one copy each
   std::vector<BufferPtr> staged;
-  std::vector<std::vector<const uint8_t*>> in_ptr(nb, std::vector<const uint8_t*>(ncols));
+  struct PtrTable {   // [batch][column], flat: one allocation for 10^5 batches
+    std::vector<const uint8_t*> v; size_t ncols;
+    const uint8_t** operator[](size_t b) { return v.data() + b * ncols; }
+  } in_ptr{std::vector<const uint8_t*>(nb * ncols), ncols};
   if (host_in) {
     for (size_t i = 0; i < ncols; ++i) {
       const int64_t w = recs[0].cols[i].width;
@@ -1162,6 +1210,20 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
     }
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   }
+  if (co) {   // the dense buffers ARE the coalesced batch
+    co->out.on_device = out_on_device; co->out.device_id = out_on_device ? ctx.device : -1;
+    co->out.nrows = total;
+    for (size_t i = 0; i < ncols; ++i) {
+      Column c = empty_like(recs[0].cols[i]);
+      const BufferPtr& buf = out_on_device ? dense[i] : host_dense[i];
+      c.values = (const uint8_t*)buf->ptr; c.length = total; c.owned.push_back(buf);
+      co->out.cols.push_back(std::move(c));
+    }
+    int64_t prev = 0;
+    for (size_t b = 0; b < nb; ++b) { co->rows.push_back((int64_t)h_cnt[b] - prev); prev = (int64_t)h_cnt[b]; }
+    co->done = true;
+    return {};
+  }
   std::vector<Batch> outs(nb);
   int64_t begin = 0;
   for (size_t b = 0; b < nb; ++b) {
@@ -1181,6 +1243,7 @@ std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, 
   }
   return outs;
 }
+}  // namespace
 
 // =================================================================================================
 // project_record / compute_value

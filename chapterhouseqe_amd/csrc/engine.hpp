@@ -153,6 +153,9 @@ Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanCo
 // one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
                                   const Expr& expr, bool out_on_device);
+// the same, but ONE output batch holding every surviving row in input order (+ surviving rows per input batch)
+Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
+                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record);
 Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_dev,
                      const std::vector<PlanColumn>& pcols);
 // filter_record + project_record in one kernel pass; false = outside its scope (or an error was flagged): run the two steps

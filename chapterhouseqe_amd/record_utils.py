@@ -401,6 +401,28 @@ def filter_records(recs, table_aliases: Optional[Sequence[Sequence[str]]], expr:
     return results
 
 
+def filter_records_coalesced(recs, table_aliases: Optional[Sequence[Sequence[str]]], expr: A.Expr, *,
+                             ctx: Optional[Context] = None, device_result: Optional[bool] = None):
+    """`filter_records` with the outputs joined (`chq_filter_records_coalesced`): returns (one batch holding the
+    surviving rows of every input batch in input order, [surviving rows per input batch])."""
+    grp = recs if isinstance(recs, RecordGroup) else RecordGroup(recs, ctx)
+    ctx = ctx or grp.ctx
+    dev_out = grp.on_device if device_result is None else device_result
+    e = _expr_to_c(expr)
+    al = _Aliases(table_aliases)
+    out = _CBatch()
+    rows = (C.c_int64 * grp.n)()
+    try:
+        rc = L.lib().chq_filter_records_coalesced(ctx.handle, grp.n, grp.ptrs, C.byref(grp.schema), al.ptr, e,
+                                                  L.ARROW_DEVICE_ROCM if dev_out else L.ARROW_DEVICE_CPU,
+                                                  C.byref(out.array), C.byref(out.schema), rows)
+    finally:
+        L.lib().chq_expr_free(e)
+        if grp is not recs:
+            grp.release()
+    return _finish(ctx, rc, out, dev_out), list(rows)
+
+
 def project_record(fields: Sequence[A.SelectItem], record: Record, table_aliases: Optional[Sequence[Sequence[str]]], *,
                    ctx: Optional[Context] = None, device_result: Optional[bool] = None):
     """RU/record_projection.rs:16-76."""

@@ -166,6 +166,17 @@ chq_status chq_filter_records(chq_ctx* ctx, int n_records, const struct ArrowDev
                               const chq_expr* expr, int out_device, struct ArrowDeviceArray* outs,
                               struct ArrowSchema* out_schemas);
 
+/* The same call with the results joined: ONE output batch = the surviving rows of recs[0], recs[1], ... back to
+ * back (input order), and rows_per_record[i] (optional, n_records entries) = how many of them came from recs[i].
+ * This is the batch coalescing the reference plans for its exchange (DEV_NOTES.md:175-182):
+ * downstream operators see one large batch instead of 10^5 small ones; a caller that needs the per-record ids back
+ * slices the output at the running sums of rows_per_record.  In the one-launch case the output IS the kernel's dense
+ * buffer, so nothing is copied or exported per input batch. */
+chq_status chq_filter_records_coalesced(chq_ctx* ctx, int n_records, const struct ArrowDeviceArray* const* recs,
+                                        const struct ArrowSchema* schema, const chq_table_aliases* table_aliases,
+                                        const chq_expr* expr, int out_device, struct ArrowDeviceArray* out,
+                                        struct ArrowSchema* out_schema, int64_t* rows_per_record);
+
 /* RU/record_projection.rs:16-76 */
 chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n_fields,
                               const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,

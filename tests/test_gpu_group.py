@@ -261,3 +261,28 @@ def test_large_group_many_small_batches(ctx):
         h = outs[b].to_host()
         lo, hi = b * rows, (b + 1) * rows
         assert np.array_equal(h.column(2).to_numpy(), cols[2][lo:hi][mask[lo:hi]].cpu().numpy())
+
+
+@pytest.mark.parametrize("device", [True, False], ids=["device", "host"])
+def test_coalesced_output_is_the_concatenation_of_the_per_batch_results(ctx, device):
+    """chq_filter_records_coalesced: one output batch = the per-batch results back to back, plus rows per input batch"""
+    cases = [
+        ([fixed_batch(n, 500 + i) for i, n in enumerate([10_000] * 12 + [3333, 2])], "value2 > 10.0"),          # one launch
+        ([fixed_batch(n, 520 + i) for i, n in enumerate(RAGGED)], "id % 2 = 0 and value1 < 20.0"),                # tile table
+        ([mixed_batch(n, 540 + n, nulls=True) for n in (100, 3000, 17, 2500)], "a > 50 or f"),                    # general columns
+        ([fixed_batch(n, 560 + n) for n in (100, 0, 1, 5000)], "value2 > 10.0"),                                  # batch by batch
+        ([fixed_batch(n, 570 + n) for n in (40, 50)], "id <> id"),                                                # nothing survives
+    ]
+    for recs, sql in cases:
+        al = empty_aliases(recs[0])
+        e = parse_expr(sql)
+        parts = [O.filter_record(r, al, e) for r in recs]
+        exp = pa.Table.from_batches(parts).combine_chunks()
+        exp = exp.to_batches()[0] if exp.num_rows else parts[0].slice(0, 0)
+        src = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs] if device else recs
+        got, rows = chq.filter_records_coalesced(src, al, e, ctx=ctx)
+        got = got.to_host() if device else got
+        assert rows == [p.num_rows for p in parts], sql
+        assert batches_identical(got, exp), f"{sql}:\n{explain_diff(got, exp)}"
+    with pytest.raises(chq.ChqError):
+        chq.filter_records_coalesced([fixed_batch(10, 1), fixed_batch(10, 2)], empty_aliases(fixed_batch(10, 1)), parse_expr("nope > 1"), ctx=ctx)
