@@ -155,11 +155,11 @@ def main():
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes of
         # this same command; the counters cannot be read from inside the process, so the committed summary is quoted)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "bench_pmc_hbm_v2.json")
+        pmc = os.path.join(ROOT, "profiles", "r1", "bench_pmc_hbm_v3.json")
         if os.path.exists(pmc) and args.predicate == PREDICATE and n == 1_000_000_000:
             j = json.load(open(pmc))
             traffic = j["fetch_bytes_corrected"] + j["write_bytes"]
-            traffic_src = "profiles/r1/bench_pmc_hbm_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)"
+            traffic_src = "profiles/r1/bench_pmc_hbm_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)"
         # a plain device copy measured in this same process, so the fraction is not hostage to the datasheet peak
         # (SURVEY.md section 8 d): one column copied into a scratch tensor, read + write bytes / time
         copy_gbps = None

@@ -73,6 +73,12 @@ extern "C" {
         table_aliases: *const chq_table_aliases, expr: *const chq_expr, out_device: c_int,
         outs: *mut ArrowDeviceArray, out_schemas: *mut FFI_ArrowSchema,
     ) -> c_int;
+    /// the same, outputs joined into one batch + surviving rows per input record
+    pub fn chq_filter_records_coalesced(
+        ctx: *mut chq_ctx, n_records: c_int, recs: *const *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
+        table_aliases: *const chq_table_aliases, expr: *const chq_expr, out_device: c_int,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema, rows_per_record: *mut i64,
+    ) -> c_int;
     pub fn chq_project_record(
         ctx: *mut chq_ctx, fields: *const chq_select_item, n_fields: c_int, rec: *const ArrowDeviceArray,
         schema: *const FFI_ArrowSchema, table_aliases: *const chq_table_aliases, out_device: c_int,
