@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "chq_abi_version", "chq_status_name", "chq_ctx_create", "chq_ctx_destroy", "chq_ctx_last_error", "chq_ctx_stream",
     "chq_ctx_set_option", "chq_ctx_last_stats", "chq_expr_identifier", "chq_expr_compound_identifier", "chq_expr_number",
     "chq_expr_boolean", "chq_expr_single_quoted_string", "chq_expr_unsupported_value", "chq_expr_binary_op",
-    "chq_expr_nested", "chq_expr_unsupported", "chq_expr_free", "chq_filter_record", "chq_filter_records", "chq_filter_records_coalesced", "chq_project_record",
+    "chq_expr_nested", "chq_expr_unsupported", "chq_expr_free", "chq_filter_record", "chq_filter_records", "chq_filter_records_coalesced", "chq_plan_describe", "chq_project_record",
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
 ]
 
@@ -132,6 +132,7 @@ def lib():
         "chq_expr_unsupported": (vp, [cp]), "chq_expr_free": (None, [vp]),
         "chq_filter_record": (ci, [vp, PDA, PS, PTA, vp, ci, PDA, PS]),
         "chq_filter_records": (ci, [vp, ci, C.POINTER(PDA), PS, PTA, vp, ci, PDA, PS]),
+        "chq_plan_describe": (ci, [PS, PTA, vp, i64, ci, C.c_char_p, C.c_size_t]),
         "chq_filter_records_coalesced": (ci, [vp, ci, C.POINTER(PDA), PS, PTA, vp, ci, PDA, PS, C.POINTER(i64)]),
         "chq_project_record": (ci, [vp, C.POINTER(SelectItem), ci, PDA, PS, PTA, ci, PDA, PS]),
         "chq_compute_value": (ci, [vp, PDA, PS, PTA, vp, ci, PDA, PS, C.POINTER(ci)]),

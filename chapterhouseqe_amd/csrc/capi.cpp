@@ -173,6 +173,22 @@ chq_status chq_filter_record(chq_ctx* ctx, const ArrowDeviceArray* rec, const Ar
   });
 }
 
+chq_status chq_plan_describe(const ArrowSchema* schema, const chq_table_aliases* table_aliases, const chq_expr* expr,
+                             int64_t n_rows, int enable_minus, char* buf, size_t buf_len) {
+  std::string text;
+  chq_status st = CHQ_OK;
+  try {
+    if (!expr) throw ChqError{CHQ_ERR_INVALID_HANDLE, "null expression"};
+    text = describe_plan(schema, table_aliases, expr->e, n_rows, enable_minus != 0);
+  } catch (const ChqError& e) {
+    st = (chq_status)e.code; text = e.msg;
+  } catch (const std::exception& e) {
+    st = CHQ_ERR_DEVICE; text = e.what();
+  }
+  if (buf && buf_len) { const size_t n = std::min(buf_len - 1, text.size()); memcpy(buf, text.data(), n); buf[n] = 0; }
+  return st;
+}
+
 chq_status chq_filter_records(chq_ctx* ctx, int n_records, const ArrowDeviceArray* const* recs, const ArrowSchema* schema,
                               const chq_table_aliases* table_aliases, const chq_expr* expr, int out_device,
                               ArrowDeviceArray* outs, ArrowSchema* out_schemas) {

@@ -1655,4 +1655,54 @@ bool filter_project_fused(Context& ctx, const Batch& rec, const std::vector<Plan
   return true;
 }
 
+// =================================================================================================
+// describe_plan: the host half of a call (typing, coercion, constant folding, lowering) without a GPU
+// =================================================================================================
+std::string describe_plan(const ArrowSchema* schema, const chq_table_aliases* aliases, const Expr& expr, int64_t nrows,
+                          bool enable_minus) {
+  if (!schema || !schema->format || strcmp(schema->format, "+s") != 0)
+    throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "record batch schema must be a struct"};
+  std::vector<PlanColumn> cols;
+  for (int64_t i = 0; i < schema->n_children; ++i) {
+    const ArrowSchema* cs = schema->children[i];
+    PlanColumn p;
+    int width = 0;
+    p.name = cs->name ? cs->name : "";
+    parse_format(cs->format, &p.type, &width);
+    p.has_nulls = (cs->flags & ARROW_FLAG_NULLABLE) != 0;
+    p.alias_entry_present = aliases ? (int)i < aliases->n_columns : true;
+    if (aliases && (int)i < aliases->n_columns)
+      for (int k = 0; k < aliases->columns[i].n; ++k) p.aliases.push_back(aliases->columns[i].aliases[k]);
+    cols.push_back(std::move(p));
+  }
+  TypedExpr te = type_expr(expr, cols, nrows, enable_minus);
+  if (te.pending_code) throw ChqError{te.pending_code, te.pending_msg};
+  const Node& root = te.at(te.root);
+  static const char* kOps[] = {"LOAD", "ADD", "SUB", "MUL", "DIV", "REM", "EQ", "NE", "LT", "LE", "GT", "GE", "AND", "OR",
+                               "CAST", "TOBOOL", "SPILL", "STRCMP", "STORE"};
+  static const char* kSrc[] = {"-", "col", "const", "tmp", "btmp"};
+  std::string out = std::string("result ") + dtype_name(root.type) + " scalar=" + (root.is_scalar ? "1" : "0") + " len1=" + (root.len1 ? "1" : "0") + "\n";
+  if (root.len1) {
+    Scalar v = fold_constant(te, te.root);
+    char hex[40];
+    snprintf(hex, sizeof hex, "%016llx", (unsigned long long)v.bits);
+    out += std::string("value ") + (v.type == T_UTF8 ? "'" + v.str + "'" : std::string("0x") + hex) + "\n";
+    return out;
+  }
+  if (root.kind == Node::COL) { out += "column " + std::to_string(root.col) + "\n"; return out; }
+  Lowered lw;
+  lower_expr(te, te.root, cols, lw);
+  out += "program wide=" + std::to_string((int)lw.wide) + " num_temps=" + std::to_string(lw.num_temps) + " refs=";
+  for (size_t i = 0; i < lw.refs.size(); ++i) out += (i ? "," : "") + std::to_string(lw.refs[i]);
+  out += "\n";
+  for (const Instr& in : lw.prog) {
+    char line[160];
+    snprintf(line, sizeof line, "  %-6s %-7s %s%s%s idx=%u%s imm=0x%llx\n", in.op < 19 ? kOps[in.op] : "?", dtype_name((DType)in.type),
+             in.src_kind < 5 ? kSrc[in.src_kind] : "?", in.src_kind == SRC_COL ? ":" : "", in.src_kind == SRC_COL ? dtype_name((DType)in.src_type) : "",
+             (unsigned)in.src_idx, (in.flags & IF_REV) ? " rev" : "", (unsigned long long)in.imm);
+    out += line;
+  }
+  return out;
+}
+
 }  // namespace chq

@@ -166,4 +166,8 @@ Column compute_value(Context& ctx, const Batch& rec_dev, const std::vector<PlanC
 
 std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* aliases);
 
+// host-only: result type / flags and the lowered device program of `expr` over a schema (text); throws the static error
+std::string describe_plan(const ArrowSchema* schema, const chq_table_aliases* aliases, const Expr& expr, int64_t nrows,
+                          bool enable_minus);
+
 }  // namespace chq

@@ -341,6 +341,27 @@ def filter_record(rec: Record, table_aliases: Optional[Sequence[Sequence[str]]],
     return _finish(ctx, rc, out, dev_out)
 
 
+def plan_describe(schema: pa.Schema, table_aliases: Optional[Sequence[Sequence[str]]], expr: A.Expr, num_rows: int = 2,
+                  enable_minus: bool = False) -> str:
+    """Host half of compute_value (typing, coercion, folding, lowering) as text -- `chq_plan_describe`; needs no GPU.
+    Raises ChqError with the static status the record calls would return."""
+    cs = L.ArrowSchema()
+    schema._export_to_c(C.addressof(cs))
+    e = _expr_to_c(expr)
+    al = _Aliases(table_aliases)
+    buf = C.create_string_buffer(8192)
+    try:
+        rc = L.lib().chq_plan_describe(C.byref(cs), al.ptr, e, num_rows, 1 if enable_minus else 0, buf, len(buf))
+    finally:
+        L.lib().chq_expr_free(e)
+        if cs.release:
+            C.CFUNCTYPE(None, C.c_void_p)(cs.release)(C.addressof(cs))
+    text = buf.value.decode(errors="replace")
+    if rc:
+        raise ChqError(rc, text)
+    return text
+
+
 class RecordGroup:
     """A prepared argument block for `filter_records`: the C pointer array over a list of same-schema batches.
     Building it once lets a caller that re-filters the same batches (benchmarks) keep Python out of the call."""

@@ -196,6 +196,15 @@ chq_status chq_filter_project_record(chq_ctx* ctx, const chq_expr* predicate, co
                                      const struct ArrowSchema* schema, const chq_table_aliases* table_aliases,
                                      int out_device, struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
 
+/* ---- host half only (no GPU, no context) --------------------------------------------------------- */
+/* Types `expr` against `schema` (a struct schema as in the record calls) exactly as chq_compute_value would --
+ * literal typing, column / alias lookup, the coercion table, constant folding, the arrow length rules -- and writes
+ * a description into `buf`: "result <Type> scalar=<0|1> len1=<0|1>", then the folded value, the column index or the
+ * listing of the device program.  Returns the static status the record calls would return for a batch of n_rows rows
+ * (message in `buf`).  Used by the CPU test tier and for debugging planners; touches no device. */
+chq_status chq_plan_describe(const struct ArrowSchema* schema, const chq_table_aliases* table_aliases,
+                             const chq_expr* expr, int64_t n_rows, int enable_minus, char* buf, size_t buf_len);
+
 /* ---- device residency helpers ----------------------------------------------------------------- */
 /* Copy a host batch into HBM / a device batch back to host memory. */
 chq_status chq_record_to_device(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
