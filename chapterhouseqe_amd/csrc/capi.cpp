@@ -19,7 +19,7 @@ chq_status guarded(chq_ctx* ctx, F&& f) {
     return CHQ_OK;
   } catch (const ChqError& e) {
     if (ctx) ctx->c.last_error = e.msg;
-    return (chq_status)e.code;
+    return e.code == CHQ_INTERNAL_PROGRAM_LIMIT ? CHQ_ERR_NOT_SUPPORTED : (chq_status)e.code;
   } catch (const std::bad_alloc&) {
     if (ctx) ctx->c.last_error = "out of host memory";
     return CHQ_ERR_OUT_OF_MEMORY;
@@ -181,7 +181,7 @@ chq_status chq_plan_describe(const ArrowSchema* schema, const chq_table_aliases*
     if (!expr) throw ChqError{CHQ_ERR_INVALID_HANDLE, "null expression"};
     text = describe_plan(schema, table_aliases, expr->e, n_rows, enable_minus != 0);
   } catch (const ChqError& e) {
-    st = (chq_status)e.code; text = e.msg;
+    st = e.code == CHQ_INTERNAL_PROGRAM_LIMIT ? CHQ_ERR_NOT_SUPPORTED : (chq_status)e.code; text = e.msg;
   } catch (const std::exception& e) {
     st = CHQ_ERR_DEVICE; text = e.what();
   }

@@ -480,6 +480,71 @@ int pick_tile_kind(const Context& ctx, const Lowered& lw, int64_t rows) {
 std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols,
                                    const std::vector<const TypedExpr*>& exprs);
 
+// ---- expressions that do not fit one device program ------------------------------------------------------------
+// The reference has no size limits (one arrow kernel per AST node).  When lower_expr reports that a typed tree needs
+// more instructions / columns / temporaries than a program holds, sub-trees are evaluated into temporary columns
+// (appended to `work` / `wcols`, never part of any output) and replaced by column nodes, bottom-up and left to right
+// -- i.e. in the reference's own evaluation order -- until the rest fits.  `strict` materialises EVERY inner node in
+// that order (exactly the reference's strategy): used to find the first data-dependent error when a materialisation
+// launch reports one, because a temporary may have been evaluated ahead of a smaller sub-tree to its left.
+bool lowers_alone(const TypedExpr& te, int node, const std::vector<PlanColumn>& wcols) {
+  try {
+    Lowered trial;
+    lower_expr(te, node, wcols, trial);
+    return (int)trial.prog.size() + 1 <= MAX_INSTR;   // room for the STORE of a materialisation
+  } catch (const ChqError& e) {
+    if (e.code == CHQ_INTERNAL_PROGRAM_LIMIT) return false;
+    throw;
+  }
+}
+bool is_leaf_node(const Node& n) { return n.kind == Node::COL || n.kind == Node::CONST; }
+
+void materialize_node(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te, int node) {
+  TypedExpr sub;
+  sub.nodes = te.nodes; sub.root = node;
+  std::vector<const TypedExpr*> one{&sub};
+  const chq_call_stats keep = ctx.stats;
+  std::vector<Column> cols = evaluate_dense(ctx, work, wcols, one);
+  ctx.stats = keep;
+  Column c = std::move(cols[0]);
+  c.name = "__chq_tmp_" + std::to_string(work.cols.size());
+  PlanColumn pc;
+  pc.name = c.name; pc.type = c.type; pc.has_nulls = c.validity && c.null_count != 0; pc.alias_entry_present = true;
+  Node repl{};
+  repl.kind = Node::COL; repl.type = te.nodes[node].type; repl.is_scalar = false; repl.len1 = false;
+  repl.col = (int)work.cols.size(); repl.ref_order = te.nodes[node].ref_order;
+  work.cols.push_back(std::move(c));
+  wcols.push_back(std::move(pc));
+  te.nodes[node] = repl;
+}
+
+void fit_subtree(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te, int node, bool strict, bool is_root) {
+  if (is_leaf_node(te.nodes[node])) return;
+  const int l = te.nodes[node].l, r = te.nodes[node].r;
+  if (l >= 0) fit_subtree(ctx, work, wcols, te, l, strict, false);
+  if (r >= 0) fit_subtree(ctx, work, wcols, te, r, strict, false);
+  if (strict) { if (!is_root) materialize_node(ctx, work, wcols, te, node); return; }
+  if (lowers_alone(te, node, wcols)) return;
+  // both children fit on their own but not together with this node: turn them into columns, left first
+  if (l >= 0 && !is_leaf_node(te.nodes[l])) materialize_node(ctx, work, wcols, te, l);
+  if (!lowers_alone(te, node, wcols) && r >= 0 && !is_leaf_node(te.nodes[r])) materialize_node(ctx, work, wcols, te, r);
+}
+
+// After this call lower_expr(te, te.root) succeeds.  `work` / `wcols` start as copies of the batch and its plan columns.
+void fit_to_device(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const TypedExpr& original,
+                   Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te) {
+  for (int pass = 0; pass < 2; ++pass) {
+    work = rec; wcols = pcols; te = original;
+    try {
+      fit_subtree(ctx, work, wcols, te, te.root, /*strict=*/pass == 1, true);
+      return;
+    } catch (const ChqError& e) {
+      const bool data_error = e.code == CHQ_ERR_ARROW_ARITHMETIC_OVERFLOW || e.code == CHQ_ERR_ARROW_DIVIDE_BY_ZERO;
+      if (pass == 1 || !data_error) throw;   // strict order reports the reference's first error
+    }
+  }
+}
+
 // type_expr + the reference's error order: data-dependent errors of subtrees evaluated before a static
 // error take precedence over it
 TypedExpr typed(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr) {
@@ -524,7 +589,17 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "Filter predicate of length " + std::to_string(mask_len) +
                                                        " is larger than target array of length " + std::to_string(nrows)};
   Lowered lw;
-  lower_expr(te, te.root, pcols, lw);
+  Batch work; std::vector<PlanColumn> wcols; TypedExpr fitted;
+  const Batch* prog_rec = &rec;   // what the program's column refs index: the batch, or the batch + temporary columns
+  try {
+    lower_expr(te, te.root, pcols, lw);
+  } catch (const ChqError& e) {
+    if (e.code != CHQ_INTERNAL_PROGRAM_LIMIT) throw;
+    fit_to_device(ctx, rec, pcols, te, work, wcols, fitted);   // sub-trees -> temporary columns until the rest fits
+    lw = Lowered{};
+    lower_expr(fitted, fitted.root, wcols, lw);
+    prog_rec = &work;
+  }
 
   Batch out;
   out.on_device = true; out.device_id = ctx.device;
@@ -591,7 +666,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
     p.sel_mask = (first && need_followup) ? (u64*)sel_mask->ptr : nullptr;
     p.grp_base = (first && need_followup) ? (u64*)grp_base->ptr : nullptr;
-    if (first) fill_refs(p.pb, lw, rec, str_bufs);
+    if (first) fill_refs(p.pb, lw, *prog_rec, str_bufs);
     else {   // later passes re-read the selection bitmap as a Boolean column
       p.pb.n_instr = 1; p.pb.n_refs = 1;
       Instr in{}; in.op = OP_LOAD; in.type = T_BOOL; in.src_kind = SRC_COL; in.src_type = T_BOOL; in.src_idx = 0;
@@ -604,6 +679,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     p.stash_ref = -1;
     if (first && ctx.opt_stash) {
       for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
+        if ((size_t)lw.refs[r] >= rec.cols.size()) continue;   // a temporary column: not an output column
         const Column& c = rec.cols[lw.refs[r]];
         if (c.type == T_BOOL || c.type == T_UTF8 || c.width > 4) continue;
         auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
@@ -1049,7 +1125,12 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   const Node& root = te.at(te.root);
   if (root.type != T_BOOL || root.len1) return per_batch_loop();
   Lowered lw;
-  lower_expr(te, te.root, pcols, lw);
+  try {
+    lower_expr(te, te.root, pcols, lw);
+  } catch (const ChqError& e) {
+    if (e.code != CHQ_INTERNAL_PROGRAM_LIMIT) throw;
+    return per_batch_loop();   // oversized predicate: every batch materialises its own temporaries
+  }
   if (!lw.strs.empty()) return per_batch_loop();
 
   ctx.stats = chq_call_stats{};
@@ -1313,6 +1394,18 @@ std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::ve
   Scratch* hs = (Scratch*)ctx.pinned;
   size_t k = 0;
   while (k < exprs.size()) {
+    if (!lowers_alone(*exprs[k], exprs[k]->root, pcols)) {
+      // too large for one program even alone: sub-trees become temporary columns first (fit_to_device), then the
+      // rest is evaluated like any other expression
+      Batch work; std::vector<PlanColumn> wcols; TypedExpr fitted;
+      fit_to_device(ctx, rec, pcols, *exprs[k], work, wcols, fitted);
+      std::vector<const TypedExpr*> one{&fitted};
+      Column c = std::move(evaluate_dense(ctx, work, wcols, one)[0]);
+      results[k] = std::move(c);
+      hs = (Scratch*)ctx.pinned; ds = dev_scratch(ctx);
+      ++k;
+      continue;
+    }
     // pack as many expressions as fit the program limits into one launch
     Lowered lw;
     std::vector<ProjItem> items;

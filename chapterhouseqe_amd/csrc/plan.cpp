@@ -400,13 +400,13 @@ struct Gen {
 
   int ref_of(int col) {
     for (size_t i = 0; i < out.refs.size(); ++i) if (out.refs[i] == col) return (int)i;
-    if ((int)out.refs.size() >= MAX_REFS) fail(CHQ_ERR_NOT_SUPPORTED, "expression references more than 12 distinct columns");
+    if ((int)out.refs.size() >= MAX_REFS) fail(CHQ_INTERNAL_PROGRAM_LIMIT, "expression references more than 12 distinct columns");
     out.refs.push_back(col);
     if (is_wide(cols[col].type)) out.wide = true;
     return (int)out.refs.size() - 1;
   }
   void emit(const Instr& in) {
-    if ((int)out.prog.size() >= MAX_INSTR) fail(CHQ_ERR_NOT_SUPPORTED, "expression needs more than 40 instructions");
+    if ((int)out.prog.size() >= MAX_INSTR) fail(CHQ_INTERNAL_PROGRAM_LIMIT, "expression needs more than 40 instructions");
     out.prog.push_back(in);
   }
   static uint64_t const_bits(const Scalar& s) { return s.bits; }
@@ -429,10 +429,10 @@ struct Gen {
   int alloc_temp(DType ty) {
     if (ty == T_BOOL) {
       for (int i = 0; i < MAX_BOOL_TEMPS; ++i) if (!bool_used[i]) { bool_used[i] = true; return i; }
-      fail(CHQ_ERR_NOT_SUPPORTED, "expression needs more than 4 boolean temporaries");
+      fail(CHQ_INTERNAL_PROGRAM_LIMIT, "expression needs more than 4 boolean temporaries");
     }
     for (int i = 0; i < MAX_NUM_TEMPS; ++i) if (!num_used[i]) { num_used[i] = true; if (i + 1 > out.num_temps) out.num_temps = i + 1; return i; }
-    fail(CHQ_ERR_NOT_SUPPORTED, "expression needs more than 2 numeric temporaries");
+    fail(CHQ_INTERNAL_PROGRAM_LIMIT, "expression needs more than 2 numeric temporaries");
   }
   void free_temp(DType ty, int i) { if (ty == T_BOOL) bool_used[i] = false; else num_used[i] = false; }
 
@@ -487,7 +487,7 @@ struct Gen {
     Instr in{};
     in.op = OP_STRCMP; in.type = T_UTF8; in.src_type = T_UTF8; in.src_kind = SRC_COL; in.ref_order = (uint8_t)n.ref_order;
     auto str_idx = [&](const Node& c) {
-      if ((int)out.strs.size() >= MAX_CONST_STR) fail(CHQ_ERR_NOT_SUPPORTED, "more than 4 string literals in one expression");
+      if ((int)out.strs.size() >= MAX_CONST_STR) fail(CHQ_INTERNAL_PROGRAM_LIMIT, "more than 4 string literals in one expression");
       out.strs.push_back(c.cval.str);
       return (uint64_t)out.strs.size() - 1;
     };

@@ -22,6 +22,9 @@ struct ChqError {
   int code;
   std::string msg;
 };
+// internal: the expression is fine but does not fit ONE device program (instruction / column / temporary limits of
+// device_program.h).  The engine reacts by evaluating sub-trees into temporary columns; at the C ABI it never appears.
+constexpr int CHQ_INTERNAL_PROGRAM_LIMIT = 1030;
 
 // ---- sqlparser::ast::Expr mirror -----------------------------------------------------------------
 struct Expr {

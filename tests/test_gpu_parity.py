@@ -334,3 +334,54 @@ def test_power_of_two_literal_divisors(ctx):
     # not powers of two, reversed operands, zero: the general path (and its errors) as before
     for sql, want in [("i32 % 3", "ok"), ("i32 / 7", "ok"), ("64 / u8", "error"), ("i32 % 0", "error"), ("u16 / 0", "error")]:
         assert check_same(ctx, rec, al, sql, "value") == want, sql
+
+
+def wide_numeric_batch(n, seed, ncols=16):
+    rng = np.random.default_rng(seed)
+    cols = {f"c{i}": pa.array(rng.integers(1, 50, n).astype(np.int32)) for i in range(ncols)}
+    cols["x"] = pa.array((rng.random(n) * 10 + 1).astype(np.float32))
+    cols["y"] = pa.array(rng.random(n) * 10 + 1)
+    cols["z"] = pa.array(np.zeros(n, dtype=np.int32))
+    cols["big"] = pa.array(np.full(n, 2**31 - 1, dtype=np.int32))
+    return pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys()))
+
+
+OVERSIZED = [
+    # more numeric temporaries than a program has
+    "((c0 + c1) * (c2 + c3)) / ((c4 + c5) * (c6 + c7)) + ((c0 + c2) * (c1 + c3)) * ((c4 + c6) * (c5 + c7))",
+    "((x + y) * (y + x)) / ((x + 1.0) * (y + 2.0)) + ((x * y) + (y / x)) * ((x + x) / (y + y))",
+    # more distinct columns than a program can reference
+    " + ".join(f"c{i}" for i in range(16)),
+    # more instructions than a program holds
+    " + ".join(f"c{i % 16} * {i + 2} % {i + 3}" for i in range(30)),
+]
+OVERSIZED_PREDICATES = [
+    " + ".join(f"c{i}" for i in range(16)) + " > 400",
+    # more boolean temporaries than a program has
+    "((c0 > c1 or c2 > c3) and (c4 > c5 or c6 > c7)) or ((c8 > c9 or c10 > c11) and (c12 > c13 or (c14 > c15 and (c0 > c2 or (c1 > c3 and (c4 > c6 or c5 > c7))))))",
+    "((c0 + c1) * (c2 + c3)) / ((c4 + c5) * (c6 + c7)) > ((c8 + c9) * (c10 + c11)) / ((c12 + c13) * (c14 + c15))",
+]
+
+
+@pytest.mark.parametrize("n", [1, 777, 20_000])
+def test_expressions_larger_than_one_device_program(ctx, n):
+    """the reference has no size limits (one arrow kernel per AST node); here sub-trees become temporary columns until
+    the rest fits one program -- values, and the error an arrow-rs evaluation would hit first, must not change"""
+    rec = wide_numeric_batch(n, 4000 + n)
+    al = empty_aliases(rec)
+    for sql in OVERSIZED:
+        assert check_same(ctx, rec, al, sql, "value") == "ok", sql
+    for sql in OVERSIZED_PREDICATES:
+        assert check_same(ctx, rec, al, sql, "filter") == "ok", sql
+        assert check_same(ctx, rec, al, sql, "value") == "ok", sql
+    # two different data-dependent errors: the small left operand (division by zero) is evaluated first by the
+    # reference, although the large right operand (overflow) is the part that gets materialised first here
+    huge_overflow = "((big + c0) * (c2 + c3)) / ((c4 + c5) * (c6 + c7)) + ((c0 + c2) * (c1 + c3)) * ((c4 + c6) * (c5 + c7))"
+    for sql in [f"(c0 / z) + ({huge_overflow})", f"({huge_overflow}) + (c0 / z)", f"(c0 / z) + ({huge_overflow}) > 0"]:
+        assert check_same(ctx, rec, al, sql, "value") == "error", sql
+    assert check_same(ctx, rec, al, f"(c0 / z) + ({huge_overflow}) > 0", "filter") == "error"
+    # a projection mixing ordinary and oversized items
+    sel = parse_select(f"select c0, {OVERSIZED[0]} as big1, c1 + 1 as small, {OVERSIZED[2]} as sum16 from t")
+    got = chq.project_record(sel.projection, rec, al, ctx=ctx)
+    exp = O.project_record(sel.projection, rec, al)
+    assert batches_identical(got, exp, nan_payload=False), explain_diff(got, exp)
