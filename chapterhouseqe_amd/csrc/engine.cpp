@@ -733,16 +733,20 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     split->bounds.assign(n, 0);
     check_hip(hipMemcpyAsync(split->bounds.data(), sp.out, n * 8, hipMemcpyDeviceToHost, ctx.stream), "read back split bounds");
   }
-  if (utf8_cols.size() > 8) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 8 Utf8 columns in one batch"};
-  if (!utf8_cols.empty()) {   // input byte span of every Utf8 column (= capacity of its output) rides on the same read-back
+  // The follow-up kernels report through the fixed-size scratch header: 16 null counters and 8 Utf8 byte spans /
+  // totals per round; wider batches simply take more rounds (each with its own read-back).
+  constexpr size_t kNullPerRound = 16, kUtf8PerRound = 8;
+  auto gather_utf8_ends = [&](size_t u0, size_t u1) {   // input byte span of Utf8 columns [u0, u1) = capacity of their outputs
+    if (u1 <= u0) return;
     GatherParams gp{};
-    for (size_t k = 0; k < utf8_cols.size(); ++k) {
+    for (size_t k = u0; k < u1; ++k) {
       const int32_t* offs = (const int32_t*)rec.cols[utf8_cols[k]].values0();
-      gp.src[2 * k] = offs; gp.src[2 * k + 1] = offs + mask_len;
+      gp.src[2 * (k - u0)] = offs; gp.src[2 * (k - u0) + 1] = offs + mask_len;
     }
-    gp.n = (int32_t)(2 * utf8_cols.size()); gp.dst = ds->utf8_ends;
+    gp.n = (int32_t)(2 * (u1 - u0)); gp.dst = ds->utf8_ends;
     check_hip(launch_gather_i32(gp, ctx.stream), "launch gather_i32_kernel");
-  }
+  };
+  gather_utf8_ends(0, std::min(kUtf8PerRound, utf8_cols.size()));   // rides on the read-back of the row count
   check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
@@ -756,7 +760,6 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     const int fgrid = (int)std::min<int64_t>((ngroups + 31) / 32, (int64_t)ctx.num_cus * 8);
     // ---- Boolean value bitmaps and validity bitmaps -------------------------------------------------
     const size_t words = (size_t)(total + 31) / 32 + 2;
-    if (nullable_cols.size() > 24) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "more than 24 nullable columns in one batch"};
     auto bit_compact = [&](const uint8_t* in_bits, int64_t bit_off, u64* zero_counter) {
       auto ob = make_device_buffer(words * 4 + 8, ctx.device);
       check_hip(hipMemsetAsync(ob->ptr, 0, words * 4 + 8, ctx.stream), "memset bits");
@@ -771,20 +774,31 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       auto ob = bit_compact(rec.cols[ci].values, rec.cols[ci].offset, nullptr);
       out.cols[ci].values = (const uint8_t*)ob->ptr; out.cols[ci].owned.push_back(ob); out.cols[ci].length = total;
     }
-    for (size_t k = 0; k < nullable_cols.size(); ++k) {
+    std::vector<BufferPtr> byte_status(utf8_cols.size());
+    size_t n0 = 0, u0 = 0;
+    for (bool first_round = true; first_round || n0 < nullable_cols.size() || u0 < utf8_cols.size(); first_round = false) {
+    const size_t n1 = std::min(n0 + kNullPerRound, nullable_cols.size()), u1 = std::min(u0 + kUtf8PerRound, utf8_cols.size());
+    if (!first_round) {   // fresh counters, and the byte spans of this round's Utf8 columns
+      check_hip(hipMemsetAsync(ds->counters, 0, sizeof(ds->counters), ctx.stream), "memset counters");
+      if (u1 > u0) {
+        gather_utf8_ends(u0, u1);
+        check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
+        check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+      }
+    }
+    for (size_t k = n0; k < n1; ++k) {
       const int ci = nullable_cols[k];
-      auto ob = bit_compact(rec.cols[ci].validity, rec.cols[ci].offset, &ds->counters[k]);
+      auto ob = bit_compact(rec.cols[ci].validity, rec.cols[ci].offset, &ds->counters[k - n0]);
       out.cols[ci].validity = (const uint8_t*)ob->ptr; out.cols[ci].owned.push_back(ob);
     }
     // ---- Utf8 columns: one fused pass each (new offsets + bytes) --------------------------------------
     // Short strings: one fused pass (new offsets + bytes, 8192-row tiles).  Long strings: offsets pass (2048-row
     // tiles) then a copy pass with one wave per 64 rows, which spreads the byte copies over far more waves.
-    std::vector<BufferPtr> byte_status(utf8_cols.size());
-    for (size_t k = 0; k < utf8_cols.size(); ++k) {
+    for (size_t k = u0; k < u1; ++k) {
       const int ci = utf8_cols[k];
       const Column& c = rec.cols[ci];
       Column& o = out.cols[ci];
-      const int64_t cap = (int64_t)hs->utf8_ends[2 * k + 1] - hs->utf8_ends[2 * k];
+      const int64_t cap = (int64_t)hs->utf8_ends[2 * (k - u0) + 1] - hs->utf8_ends[2 * (k - u0)];
       const bool fused = cap <= mask_len * 24;
       const int64_t utiles = (mask_len + (fused ? 8191 : 2047)) / (fused ? 8192 : 2048);
       auto offb = make_device_buffer((size_t)(total + 2) * 4, ctx.device);
@@ -797,7 +811,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       up.out_offsets = (int32_t*)offb->ptr; up.out_data = (uint8_t*)db->ptr;
       up.byte_status = (u64*)byte_status[k]->ptr;
       up.ticket = (uint32_t*)((uint8_t*)byte_status[k]->ptr + (size_t)(utiles + 64) * 8);
-      up.total_bytes = &ds->counters[16 + k];   // counters[16..23] reserved for byte totals
+      up.total_bytes = &ds->counters[kNullPerRound + (k - u0)];   // counters[16..23]: byte totals
       up.rows_out = total;
       if (fused) {
         check_hip(launch_utf8_filter(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 2), ctx.stream), "launch utf8_filter_kernel");
@@ -812,10 +826,12 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     }
     check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
-    for (size_t k = 0; k < nullable_cols.size(); ++k) {
+    for (size_t k = n0; k < n1; ++k) {
       Column& o = out.cols[nullable_cols[k]];
-      o.null_count = (int64_t)hs->counters[k];
+      o.null_count = (int64_t)hs->counters[k - n0];
       if (o.null_count == 0) o.validity = nullptr;   // arrow drops an all-valid null buffer
+    }
+    n0 = n1; u0 = u1;
     }
   }
   for (Column& o : out.cols) o.length = total;

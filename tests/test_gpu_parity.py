@@ -385,3 +385,32 @@ def test_expressions_larger_than_one_device_program(ctx, n):
     got = chq.project_record(sel.projection, rec, al, ctx=ctx)
     exp = O.project_record(sel.projection, rec, al)
     assert batches_identical(got, exp, nan_payload=False), explain_diff(got, exp)
+
+
+def test_many_nullable_and_string_columns(ctx):
+    """40 nullable Int32, 20 Utf8 (half of them nullable) and 6 Boolean columns: the follow-up kernels report through a
+    fixed-size header (16 null counters, 8 Utf8 spans per round), wider batches take several rounds"""
+    n = 3000
+    rng = np.random.default_rng(23)
+    arrays, names = [], []
+    for i in range(40):
+        arrays.append(pa.array(rng.integers(0, 100, n).astype(np.int32), mask=rng.random(n) < (0.02 * (i % 5))))
+        names.append(f"n{i}")
+    words = np.array(["", "a", "bb", "ccc", "a somewhat longer string " * 3])
+    for i in range(20):
+        arrays.append(pa.array(words[rng.integers(0, len(words), n)], type=pa.utf8(), mask=(rng.random(n) < 0.1) if i % 2 else None))
+        names.append(f"s{i}")
+    for i in range(6):
+        arrays.append(pa.array(rng.integers(0, 2, n).astype(bool), mask=(rng.random(n) < 0.2) if i % 3 == 0 else None))
+        names.append(f"b{i}")
+    rec = pa.RecordBatch.from_arrays(arrays, names=names)
+    al = empty_aliases(rec)
+    for sql in ["n1 > 50", "n39 > 20 and s19 <> 'a'", "b0 or n7 % 2 = 0", "s0 >= 'b' or b5"]:
+        assert check_same(ctx, rec, al, sql, "filter") == "ok", sql
+    # host groups of such batches go through the same code once, concatenated
+    parts = [rec.slice(0, 1000), rec.slice(1000, 1500), rec.slice(2500, 500)]
+    e = parse_expr("n39 > 20 and s19 <> 'a'")
+    got = chq.filter_records(parts, al, e, ctx=ctx)
+    for g, p in zip(got, parts):
+        exp = O.filter_record(p, al, e)
+        assert batches_identical(g, exp), explain_diff(g, exp)
