@@ -1180,17 +1180,42 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactPara
 //           neighbour lane; wave / tile byte totals
 //   chained scan over the tiles' byte totals (same look-back as the row scan)
 //   pass 2: per 64-row group: exclusive scan of the lengths -> new offsets (written at the group's output row
-//           position, known from the main kernel's grp_base), then the bytes are copied in 4-byte chunks: one lane
-//           per row for short strings, half a wave per row for long ones
+//           position, known from the main kernel's grp_base), then the bytes are copied: one lane per row in 4-byte
+//           chunks for short strings, eight lanes per row in 16-byte chunks for long ones (copy_rows_wide)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void copy_row_chunks(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int len, int first, int step) {
-  for (int b = first * 4; b + 4 <= len; b += step * 4) {
-    uint32_t w;
-    __builtin_memcpy(&w, src + b, 4);
-    __builtin_memcpy(dst + b, &w, 4);
+
+// Long strings of one 64-row group: lane k holds (src offset, length, dst offset) of the selected row of rank k.
+// Eight lanes per row move 16-byte chunks (128 bytes per pass), eight rows per step; the first pass of TWO steps is
+// loaded before anything is stored, so 16 rows' loads are in flight together instead of one dependent load/store pair
+// per two rows.
+__device__ __forceinline__ void copy_rows_wide(const uint8_t* __restrict__ in_data, uint8_t* __restrict__ out_base,
+                                               int rs, int rl, int rd, int cnt, int lane) {
+  const int sub = lane >> 3, sl = lane & 7;
+  for (int k = 0; k < cnt; k += 16) {
+    const int ra = k + sub, rb = k + 8 + sub;
+    const int ia = ra < cnt ? ra : cnt - 1, ib = rb < cnt ? rb : cnt - 1;
+    // (all lanes take part in every shuffle: a lane disabled at the time would not supply its value)
+    const int sa = __shfl(rs, ia, 64), da = __shfl(rd, ia, 64), sb = __shfl(rs, ib, 64), db = __shfl(rd, ib, 64);
+    int la = __shfl(rl, ia, 64), lb = __shfl(rl, ib, 64);
+    if (ra >= cnt) la = 0;
+    if (rb >= cnt) lb = 0;
+    const uint8_t* pa = in_data + sa; uint8_t* qa = out_base + da;
+    const uint8_t* pb = in_data + sb; uint8_t* qb = out_base + db;
+    uint4 wa, wb;
+    const bool ha = sl * 16 + 16 <= la, hb = sl * 16 + 16 <= lb;
+    if (ha) __builtin_memcpy(&wa, pa + sl * 16, 16);
+    if (hb) __builtin_memcpy(&wb, pb + sl * 16, 16);
+    if (ha) __builtin_memcpy(qa + sl * 16, &wa, 16);
+    if (hb) __builtin_memcpy(qb + sl * 16, &wb, 16);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // further passes of rows longer than 128 bytes, then the tail (< 16 bytes)
+      const uint8_t* ps = h ? pb : pa; uint8_t* qd = h ? qb : qa; const int len = h ? lb : la;
+      for (int b = 128 + sl * 16; b + 16 <= len; b += 128) { uint4 w; __builtin_memcpy(&w, ps + b, 16); __builtin_memcpy(qd + b, &w, 16); }
+      const int tail = len & ~15, rem = len & 15;
+      if (sl * 4 + 4 <= rem) { uint32_t w; __builtin_memcpy(&w, ps + tail + sl * 4, 4); __builtin_memcpy(qd + tail + sl * 4, &w, 4); }
+      if (sl < (rem & 3)) qd[tail + (rem & ~3) + sl] = ps[tail + (rem & ~3) + sl];
+    }
   }
-  const int tail = len & ~3;
-  if (first < (len & 3)) dst[tail + first] = src[tail + first];
 }
 
 template <int BLOCK, int G>
@@ -1306,13 +1331,7 @@ __global__ __launch_bounds__(BLOCK) void utf8_filter_kernel(const Utf8Params p) 
       const int rs = __builtin_amdgcn_ds_permute((int)(dl << 2), src[g]);
       const int rl = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)len[g]);
       const int rd = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)dsto[g]);
-      const int half = lane >> 5, hl = lane & 31;
-      for (int k = 0; k < cnt; k += 2) {
-        const int r = k + half;
-        const int rr = r < cnt ? r : cnt - 1;
-        const int sr = __shfl(rs, rr, 64), lr = __shfl(rl, rr, 64), dr = __shfl(rd, rr, 64);
-        if (r < cnt) copy_row_chunks(p.in_data + sr, gdst + dr, lr, hl, 32);
-      }
+      copy_rows_wide(p.in_data, gdst, rs, rl, rd, cnt, lane);
     }
     __syncthreads();
   }
@@ -1423,14 +1442,8 @@ __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
         for (; b < mylen; ++b) dst[b] = src[b];
       }
     } else {
-      // long strings: half a wave per row, two rows per step
-      const int half = lane >> 5, hl = lane & 31;
-      for (int k = 0; k < cnt; k += 2) {
-        const int r = k + half;
-        const int rr = r < cnt ? r : cnt - 1;
-        const int sr = __shfl(src0, rr, 64), lr = __shfl(len0, rr, 64), dr = __shfl(dst0, rr, 64);
-        if (r < cnt) copy_row_chunks(p.in_data + sr, p.out_data + dbase + dr, lr, hl, 32);
-      }
+      // long strings: eight lanes per row, 16-byte chunks, sixteen rows in flight
+      copy_rows_wide(p.in_data, p.out_data + dbase, src0, len0, dst0, cnt, lane);
     }
   }
 }
