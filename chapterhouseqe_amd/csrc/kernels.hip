@@ -1410,40 +1410,57 @@ __global__ __launch_bounds__(BLOCK) void utf8_offsets_kernel(const Utf8Params p)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
   constexpr int NW = BLOCK / 64;
+  constexpr int U = 2;   // groups in flight per wave: the dependent loads (mask -> offsets, group base -> byte base)
+                         // of both are issued back to back, which hides half of the latency chain
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ngroups = (p.nrows + 63) >> 6;
-  for (int64_t g = (int64_t)blockIdx.x * NW + wv; g < ngroups; g += (int64_t)gridDim.x * NW) {
-    const int64_t r0 = g << 6;
-    const u64 m = p.sel_mask[g] & active_mask(r0, p.nrows);
-    if (!m) continue;
-    const bool sel = (m >> lane) & 1;
-    int32_t s0 = 0, s1 = 0;
-    if (sel) { const int32_t* o = p.in_offsets + r0 + lane; s0 = o[0]; s1 = o[1]; }
-    const int cnt = __popcll(m);
-    const unsigned dstl = sel ? lane_rank(m) : 63u - lane_rank(~m);
-    // lane k now describes the selected row of rank k
-    const int src0 = __builtin_amdgcn_ds_permute((int)(dstl << 2), s0);
-    const int len0 = __builtin_amdgcn_ds_permute((int)(dstl << 2), s1 - s0);
-    const int64_t dbase = p.out_offsets[p.grp_base[g]];   // bytes of this group are contiguous in the output
-    int inc = lane < cnt ? len0 : 0;
-    const int mylen = inc;
+  const int64_t stride = (int64_t)gridDim.x * NW;
+  for (int64_t g0 = (int64_t)blockIdx.x * NW + wv; g0 < ngroups; g0 += stride * U) {
+    u64 m[U]; int32_t s0[U], s1[U]; u64 gb[U]; int64_t dbase[U];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    const int dst0 = inc - mylen;
-    const int group_bytes = __shfl(inc, 63, 64);
-    if (group_bytes <= cnt * 24) {
-      // short strings: one lane per row
-      if (lane < cnt) {
-        const uint8_t* src = p.in_data + src0;
-        uint8_t* dst = p.out_data + dbase + dst0;
-        int b = 0;
-        for (; b + 4 <= mylen; b += 4) { uint32_t w; __builtin_memcpy(&w, src + b, 4); __builtin_memcpy(dst + b, &w, 4); }
-        for (; b < mylen; ++b) dst[b] = src[b];
+    for (int i = 0; i < U; ++i) {
+      const int64_t g = g0 + i * stride;
+      m[i] = g < ngroups ? (p.sel_mask[g] & active_mask(g << 6, p.nrows)) : 0ULL;
+      gb[i] = g < ngroups ? p.grp_base[g] : 0ULL;
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const int64_t g = g0 + i * stride;
+      s0[i] = 0; s1[i] = 0; dbase[i] = 0;
+      if (m[i]) {
+        if ((m[i] >> lane) & 1) { const int32_t* o = p.in_offsets + (g << 6) + lane; s0[i] = o[0]; s1[i] = o[1]; }
+        dbase[i] = p.out_offsets[gb[i]];   // bytes of this group are contiguous in the output
       }
-    } else {
-      // long strings: eight lanes per row, 16-byte chunks, sixteen rows in flight
-      copy_rows_wide(p.in_data, p.out_data + dbase, src0, len0, dst0, cnt, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      if (!m[i]) continue;
+      const bool sel = (m[i] >> lane) & 1;
+      const int cnt = __popcll(m[i]);
+      const unsigned dstl = sel ? lane_rank(m[i]) : 63u - lane_rank(~m[i]);
+      // lane k now describes the selected row of rank k
+      const int src0 = __builtin_amdgcn_ds_permute((int)(dstl << 2), s0[i]);
+      const int len0 = __builtin_amdgcn_ds_permute((int)(dstl << 2), s1[i] - s0[i]);
+      int inc = lane < cnt ? len0 : 0;
+      const int mylen = inc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+      const int dst0 = inc - mylen;
+      const int group_bytes = __shfl(inc, 63, 64);
+      if (group_bytes <= cnt * 24) {
+        // short strings: one lane per row
+        if (lane < cnt) {
+          const uint8_t* src = p.in_data + src0;
+          uint8_t* dst = p.out_data + dbase[i] + dst0;
+          int b = 0;
+          for (; b + 4 <= mylen; b += 4) { uint32_t w; __builtin_memcpy(&w, src + b, 4); __builtin_memcpy(dst + b, &w, 4); }
+          for (; b < mylen; ++b) dst[b] = src[b];
+        }
+      } else {
+        // long strings: eight lanes per row, 16-byte chunks, sixteen rows in flight
+        copy_rows_wide(p.in_data, p.out_data + dbase[i], src0, len0, dst0, cnt, lane);
+      }
     }
   }
 }
