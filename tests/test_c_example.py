@@ -1,0 +1,34 @@
+"""The C ABI from plain C (examples/c_abi_demo.c, gcc, no Python / torch / C++ on the caller's side): every entry point
+of the path -- chq_filter_record, chq_filter_records, chq_filter_records_coalesced, chq_filter_project_record -- over
+hand-built Arrow C Data structs, checked inside the program against a scalar loop."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "c_abi_demo")
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "chapterhouseqe_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "examples")], check=True)
+
+
+def test_demo_builds_and_fails_loudly_without_a_gpu():
+    build()
+    assert os.path.exists(EXE)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test below")
+    r = subprocess.run([EXE, "1000", "4"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "chq_ctx_create" in r.stderr   # no CPU fallback: the context cannot be created
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,batches", [(10_000, 64), (3, 5), (70_001, 7)])
+def test_demo_matches_its_scalar_loop(rows, batches):
+    build()
+    r = subprocess.run([EXE, str(rows), str(batches)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches against the scalar loop: 0" in r.stdout
