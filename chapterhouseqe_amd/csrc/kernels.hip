@@ -1,8 +1,10 @@
 // kernels.hip -- hand-written gfx950 kernels for the filter / projection record path.
 //
 // What each kernel replaces in the reference (RU = src/handlers/operator_handler/operators/record_utils):
-//   filter_fused_kernel   RU/filter_record.rs:21-39  = compute_value (predicate) + arrow filter_record_batch
+//   filter_fused_kernel   RU/filter_record.rs:21-39  = compute_value (predicate) + arrow filter_record_batch;
+//                         also the one-launch form of the caller's loop over many batches (filter_task.rs:78-126)
 //   project_kernel        RU/record_projection.rs:16-76 = one compute_value per SelectItem
+//   filter_project_kernel both of the above in one pass (filter_task.rs:99 -> materialize_files_task.rs:110)
 //   bit_compact_kernel    arrow-select filter of Boolean values / validity bitmaps
 //   utf8_*_kernel         arrow-select filter of Utf8 (offset rebuild + byte copy)
 //
@@ -193,10 +195,6 @@ struct Interp {
 #pragma unroll
       for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
     }
-  }
-  __device__ __forceinline__ int off(int j) const {  // clamped element offset of (j, lane) inside the wave's rows
-    int o = j * 64 + lane;
-    return o < nact ? o : nact - 1;
   }
   __device__ __forceinline__ u64 group_act(int j) const { return active_mask(w0 + 64 * j, nrows); }
   // per-lane flags (bit j) from a bitmap
