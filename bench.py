@@ -194,7 +194,7 @@ def main():
                          "device_copy_GBps_same_run": copy_gbps,
                          "frac_of_device_copy": (achieved / copy_gbps) if (achieved and copy_gbps) else None},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N = 1 only
             import pyarrow as pa
             from oracle import oracle as O
             m = min(n, args.cpu_rows)
