@@ -76,3 +76,38 @@ def test_idempotence_and_empty_result():
     none = chq.filter_record(rec, al, parse_expr("value2 > 1000.0"), ctx=ctx)
     assert none.num_rows == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("rows_per_batch,nb", [(10_000, 100_000), (9_999, 50_000)])
+def test_reference_sized_batches_full_size_group(rows_per_batch, nb):
+    """config 2 cut into the reference's 10 000-row batches (physical_planner.rs:323): 10^5 batches = 1 B rows through ONE
+    chq_filter_records_coalesced call -- per-batch counts and the joined output against torch"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = rows_per_batch * nb
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xBEEF)
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    v1 = torch.empty(n, dtype=torch.float32, device=dev).uniform_(0, 100, generator=g)
+    v2 = torch.empty(n, dtype=torch.float32, device=dev).uniform_(0, 100, generator=g)
+    ctx = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    recs = [chq.DeviceRecordBatch.from_device_pointers(
+        [("id", "i", ids.data_ptr() + 4 * b * rows_per_batch), ("value1", "f", v1.data_ptr() + 4 * b * rows_per_batch),
+         ("value2", "f", v2.data_ptr() + 4 * b * rows_per_batch)], rows_per_batch, ctx=ctx) for b in range(nb)]
+    grp = chq.RecordGroup(recs, ctx)
+    out, rows = chq.filter_records_coalesced(grp, [[], [], []], parse_expr("value2 > 10.0"), ctx=ctx)
+    st = ctx.last_stats()
+    mask = v2 > 10.0
+    exp_rows = mask.view(nb, rows_per_batch).sum(dim=1)
+    assert torch.equal(torch.tensor(rows, dtype=torch.int64), exp_rows.cpu())          # every batch's count
+    m = int(exp_rows.sum().item())
+    assert out.num_rows == m and st["rows_in"] == n and st["launches"] == 1
+    for i, src in enumerate([ids, v1, v2]):                                             # the joined output, bit for bit
+        t = torch.empty(m, dtype=src.dtype, device=dev)
+        _dtod(t, out.column_buffer_address(i, 1), m * 4)
+        exp = torch.masked_select(src, mask)
+        assert torch.equal(exp.view(torch.int32), t.view(torch.int32))
+        del exp, t
+    out.release()
+    grp.release()
+    ctx.close()
