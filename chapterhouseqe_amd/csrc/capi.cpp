@@ -371,6 +371,9 @@ chq_status chq_wrap_columns(chq_ctx* ctx, const chq_column_desc* cols, int n_col
         Batch probe = import_batch(&da, &parent);
         c.type = probe.cols[0].type; c.width = probe.cols[0].width;
       }
+      if (n_rows > 0 && !cols[i].values) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "column '" + c.name + "' has no values buffer"};
+      if (cols[i].null_count > 0 && !cols[i].validity) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "column '" + c.name + "' reports nulls but has no validity bitmap"};
+      if (n_rows < 0 || cols[i].offset < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "negative length or offset"};
       c.nullable = cols[i].nullable != 0; c.length = n_rows; c.null_count = cols[i].validity ? cols[i].null_count : 0; c.offset = cols[i].offset;
       c.validity = (const uint8_t*)cols[i].validity; c.values = (const uint8_t*)cols[i].values; c.data = (const uint8_t*)cols[i].data;
       b.cols.push_back(std::move(c));

@@ -190,7 +190,14 @@ Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema) {
     c.format = cs->format ? cs->format : "";
     parse_format(cs->format, &c.type, &c.width);
     c.nullable = (cs->flags & ARROW_FLAG_NULLABLE) != 0;
+    if (!ca || !cs) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "missing child array or schema"};
     if (ca->length < b.nrows) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "column shorter than the record batch"};
+    if (ca->offset < 0 || b.nrows < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "negative length or offset"};
+    // a kernel must never be handed a null data pointer: refuse malformed arrays here, on the host
+    if (b.nrows > 0 && (ca->n_buffers < 2 || !ca->buffers || !ca->buffers[1]))
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, std::string("column '") + (cs->name ? cs->name : "") + "' has no values buffer"};
+    if (ca->null_count > 0 && (ca->n_buffers < 1 || !ca->buffers[0]))
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, std::string("column '") + (cs->name ? cs->name : "") + "' reports nulls but has no validity bitmap"};
     c.length = b.nrows;
     c.offset = ca->offset;
     c.validity = ca->n_buffers > 0 ? (const uint8_t*)ca->buffers[0] : nullptr;
@@ -198,6 +205,13 @@ Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema) {
     c.data = ca->n_buffers > 2 ? (const uint8_t*)ca->buffers[2] : nullptr;
     c.null_count = ca->null_count;   // -1 = unknown, resolved when staged
     if (!c.validity) c.null_count = 0;
+    if (c.type == T_UTF8 && b.nrows > 0 && !c.data) {
+      // legal only when every string is empty; host batches can be checked, device batches are taken at their word
+      if (!b.on_device) {
+        const int32_t* offs = (const int32_t*)c.values + c.offset;
+        if (offs[b.nrows] != offs[0]) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "Utf8 column '" + c.name + "' has offsets but no data buffer"};
+      }
+    }
     b.cols.push_back(std::move(c));
   }
   return b;

@@ -308,6 +308,39 @@ def test_errors_leave_no_partial_output_and_context_stays_usable(ctx):
     assert check_same(ctx, rec, al, "i32 > 0", "filter") == "ok"
 
 
+def test_malformed_arrays_are_refused_on_the_host(ctx):
+    """a kernel must never see a null data pointer: arrays without the buffers their length needs fail with
+    ArrowError::InvalidArgument before anything is launched"""
+    good = chq.DeviceRecordBatch.from_host(pa.RecordBatch.from_arrays([pa.array(np.arange(100, dtype=np.int32))], names=["a"]), ctx)
+    addr = good.column_buffer_address(0, 1)
+    e = parse_expr("a > 5")
+    cases = [
+        [{"name": "a", "format": "i", "values": 0}],                                              # no values buffer
+        [{"name": "a", "format": "i", "values": addr, "null_count": 3, "validity": 0}],          # nulls without a bitmap
+        [{"name": "a", "format": "i", "values": addr}, {"name": "s", "format": "u", "values": 0}],  # Utf8 without offsets
+    ]
+    for cols in cases:
+        with pytest.raises(chq.ChqError) as ei:     # chq_wrap_columns refuses them ...
+            chq.DeviceRecordBatch.from_device_buffers(cols, 100, ctx)
+        assert ei.value.code == 22, cols
+    # ... and so does the import of hand-built Arrow structs on every record call
+    import ctypes as C
+    cb = good._cb
+    child = cb.array.array.children[0].contents
+    saved = child.buffers[1]
+    child.buffers[1] = None
+    try:
+        for call in (lambda: chq.filter_record(good, [[]], e, ctx=ctx), lambda: chq.filter_records([good, good], [[]], e, ctx=ctx),
+                     lambda: chq.compute_value(good, [[]], e, ctx=ctx)):
+            with pytest.raises(chq.ChqError) as ei:
+                call()
+            assert ei.value.code == 22
+    finally:
+        child.buffers[1] = saved
+    del C
+    assert chq.filter_record(good, [[]], e, ctx=ctx).num_rows == 94
+
+
 def test_power_of_two_literal_divisors(ctx):
     """x / 2^k and x % 2^k with a literal divisor take a shift/mask path on the device: truncation toward zero and the
     sign of the dividend must survive it, for every 32-bit-class integer type and the extremes"""
