@@ -1495,7 +1495,18 @@ std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::ve
     ++ctx.stats.launches;
     check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
-    if (hs->err != ERR_NONE) throw_device_error(hs->err);
+    if (hs->err != ERR_NONE) {
+      // Several expressions shared the launch and each numbers its nodes from zero, so the smallest (node, row) key may
+      // belong to a later select item.  The reference evaluates the items one after the other: do the same to find
+      // the error it would have reported.
+      if (items.size() > 1) {
+        for (const ProjItem& it : items) {
+          std::vector<const TypedExpr*> one{exprs[it.out_index]};
+          (void)evaluate_dense(ctx, rec, pcols, one);   // throws at the first failing item
+        }
+      }
+      throw_device_error(hs->err);
+    }
     for (const ProjItem& it : items) {
       Column& o = results[it.out_index];
       if (it.null_slot >= 0) { o.null_count = (int64_t)hs->counters[it.null_slot]; if (o.null_count == 0) o.validity = nullptr; }

@@ -410,6 +410,14 @@ struct Interp {
           case OP_ADD: w = a + b; break; case OP_SUB: w = a - b; break; case OP_MUL: w = a * b; break;
           case OP_DIV: w = a / b; break; default: w = fmodf(a, b); break;
         }
+        // an invalid operation on non-NaN inputs (0/0, inf + -inf, 0 * inf, fmod(x, 0)) yields the DEFAULT NaN, whose
+        // sign is a property of the machine: the reference's hosts (x86-64 SSE) produce 0xFFC00000, gfx950 0x7FC00000.
+        // arrow's comparisons are totalOrder, so the sign decides whether `nan < x` holds: follow the reference's host.
+        if (w != w && a == a && b == b) w = __uint_as_float(0xFFC00000u);
+        // NaN operands: SSE returns the first NaN operand, quieted (glibc's fmod reaches the same value through
+        // (x * y) / (x * y)); the GPU's fmod and a commuted hardware add / mul may pick the other one or a canonical NaN
+        if (a != a) w = __uint_as_float(__float_as_uint(a) | 0x00400000u);
+        else if (b != b) w = __uint_as_float(__float_as_uint(b) | 0x00400000u);
         lo[j] = __float_as_uint(w);
       }
     } else if constexpr (WIDE) {
@@ -459,6 +467,9 @@ struct Interp {
             case OP_ADD: w = a + b; break; case OP_SUB: w = a - b; break; case OP_MUL: w = a * b; break;
             case OP_DIV: w = a / b; break; default: w = fmod(a, b); break;
           }
+          if (w != w && a == a && b == b) w = __longlong_as_double((long long)0xFFF8000000000000ULL);   // x86-64 default NaN (see above)
+          if (a != a) w = __longlong_as_double(__double_as_longlong(a) | 0x0008000000000000LL);
+          else if (b != b) w = __longlong_as_double(__double_as_longlong(b) | 0x0008000000000000LL);
           const uint64_t u = (uint64_t)__double_as_longlong(w);
           lo[j] = (uint32_t)u; hi[j] = (uint32_t)(u >> 32);
         }

@@ -1,0 +1,112 @@
+"""Long-running parity fuzz (not collected by pytest): random predicates / value expressions / projections / groups over
+all column kinds and tile-boundary sizes, GPU (through the C ABI) against the CPU oracle -- values and status codes.
+
+    python -m tests.fuzz_long [seconds] [seed]
+"""
+import sys
+import time
+
+import numpy as np
+import pyarrow as pa
+
+import chapterhouseqe_amd as chq
+from chapterhouseqe_amd.sqlparse import parse_expr, parse_select
+from oracle import oracle as O
+
+from .cases import empty_aliases
+from .helpers import arrays_identical, batches_identical, explain_diff
+from .test_gpu_parity import make_batch, random_numeric, random_predicate
+
+SIZES = [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 4100, 16383, 16384, 16385, 33000, 70001]
+
+
+def outcome(fn):
+    try:
+        return None, fn()
+    except (chq.ChqError, O.OracleError) as e:
+        return e.code, None
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctxs = []
+    for kind in (-1, 0, 1, 2):
+        c = chq.Context(0)
+        c.set_option("tile_kind", kind)
+        ctxs.append(c)
+    t0 = time.time()
+    stats = {"filter": 0, "value": 0, "project": 0, "group": 0, "errors": 0, "unsupported": 0}
+    it = 0
+    while time.time() - t0 < budget:
+        it += 1
+        n = int(rng.choice(SIZES))
+        rec = make_batch(n, int(rng.integers(0, 2**31)), nulls=bool(rng.random() < 0.7))
+        if rng.random() < 0.3 and n > 10:
+            start = int(rng.integers(0, min(9, n - 1)))
+            rec = rec.slice(start, n - start - int(rng.integers(0, 3)))
+        al = empty_aliases(rec)
+        ctx = ctxs[int(rng.integers(0, len(ctxs)))]
+        mode = rng.random()
+        if mode < 0.45:
+            sql = random_predicate(rng, int(rng.integers(1, 4)))
+            e = parse_expr(sql)
+            ec, exp = outcome(lambda: O.filter_record(rec, al, e))
+            src = chq.DeviceRecordBatch.from_host(rec, ctx) if rng.random() < 0.5 else rec
+            gc, got = outcome(lambda: chq.filter_record(src, al, e, ctx=ctx))
+            if got is not None and hasattr(got, "to_host"):
+                got = got.to_host()
+            kind = "filter"
+            same = got is None or batches_identical(got, exp)
+        elif mode < 0.7:
+            sql = random_numeric(rng, 3) if rng.random() < 0.6 else random_predicate(rng, 2)
+            e = parse_expr(sql)
+            ec, exp = outcome(lambda: O.compute_value(rec, al, e)[0])
+            gc, got = outcome(lambda: chq.compute_value(rec, al, e, ctx=ctx)[0])
+            kind = "value"
+            same = got is None or arrays_identical(got, exp, nan_payload=True)
+        elif mode < 0.85:
+            items = ", ".join([random_numeric(rng, 2) + f" as c{k}" for k in range(int(rng.integers(1, 4)))] + (["*"] if rng.random() < 0.3 else []))
+            sql = f"select {items} from t where {random_predicate(rng, 2)}"
+            sel = parse_select(sql)
+            ec, exp = outcome(lambda: O.project_record(sel.projection, O.filter_record(rec, al, sel.selection), al))
+            if rng.random() < 0.5:
+                ctx.set_option("fuse", 2)
+            gc, got = outcome(lambda: chq.filter_project_record(sel.selection, sel.projection, rec, al, ctx=ctx))
+            ctx.set_option("fuse", 1)
+            kind = "project"
+            same = got is None or batches_identical(got, exp, nan_payload=True)
+        else:
+            sql = random_predicate(rng, 2)
+            e = parse_expr(sql)
+            k = int(rng.integers(2, 6))
+            cut = sorted(set(int(x) for x in rng.integers(0, max(1, rec.num_rows), k)))
+            parts = [rec.slice(a, b - a) for a, b in zip([0] + cut, cut + [rec.num_rows])]
+            ec, exp = outcome(lambda: [O.filter_record(p, al, e) for p in parts])
+            gc, got = outcome(lambda: chq.filter_records(parts, al, e, ctx=ctx))
+            kind = "group"
+            same = got is None or all(batches_identical(g, x) for g, x in zip(got, exp))
+        stats[kind] += 1
+        if ec == 30 or gc == 30:
+            stats["unsupported"] += 1
+            continue
+        if ec is not None or gc is not None:
+            stats["errors"] += 1
+            if ec != gc:
+                print(f"STATUS MISMATCH [{kind}] n={rec.num_rows}: oracle {ec}, gpu {gc}: {sql}", flush=True)
+                return 1
+            continue
+        if not same:
+            print(f"VALUE MISMATCH [{kind}] n={rec.num_rows}: {sql}", flush=True)
+            if kind in ("filter", "project"):
+                print(explain_diff(got, exp))
+            return 1
+        if it % 200 == 0:
+            print(f"{it} cases, {time.time() - t0:.0f} s: {stats}", flush=True)
+    print(f"OK: {it} cases in {time.time() - t0:.0f} s: {stats}", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -36,7 +36,7 @@ def run_fused(ctx, rec, sql, expect_fused=True, device=True):
     got = chq.filter_project_record(sel.selection, sel.projection, src, al, ctx=ctx)
     st = ctx.last_stats()
     got = got.to_host() if device else got
-    assert batches_identical(got, exp, nan_payload=False), f"{sql} (n={rec.num_rows}):\n{explain_diff(got, exp)}"
+    assert batches_identical(got, exp, nan_payload=True), f"{sql} (n={rec.num_rows}):\n{explain_diff(got, exp)}"
     if expect_fused is not None:
         assert (st["launches"] == 1) == expect_fused, (sql, st)
     return st
