@@ -37,7 +37,7 @@ def main():
         c.set_option("tile_kind", kind)
         ctxs.append(c)
     t0 = time.time()
-    stats = {"filter": 0, "value": 0, "project": 0, "group": 0, "errors": 0, "unsupported": 0}
+    stats = {"filter": 0, "value": 0, "project": 0, "group": 0, "deep": 0, "group1": 0, "errors": 0, "unsupported": 0}
     it = 0
     while time.time() - t0 < budget:
         it += 1
@@ -77,6 +77,43 @@ def main():
             ctx.set_option("fuse", 1)
             kind = "project"
             same = got is None or batches_identical(got, exp, nan_payload=True)
+        elif mode < 0.9:
+            # deep expressions: beyond one device program -> sub-trees become temporary columns (fit_to_device)
+            sql = random_numeric(rng, int(rng.integers(4, 7))) if rng.random() < 0.5 else random_predicate(rng, int(rng.integers(3, 5)))
+            e = parse_expr(sql)
+            ec, exp = outcome(lambda: O.compute_value(rec, al, e)[0])
+            src = chq.DeviceRecordBatch.from_host(rec, ctx) if rng.random() < 0.5 else rec
+            gc, got = outcome(lambda: chq.compute_value(src, al, e, ctx=ctx)[0])
+            kind = "deep"
+            same = got is None or arrays_identical(got, exp, nan_payload=True)
+        elif mode < 0.95:
+            # numeric-only batches: the one-launch group path (wave-packed or tile table), per-batch and coalesced
+            keep = [i for i, f in enumerate(rec.schema) if f.name in ("i8", "i16", "i32", "u8", "u16", "f32", "f64", "i64", "small")]
+            num = pa.RecordBatch.from_arrays([pa.array(rec.column(i).to_numpy(zero_copy_only=False)) if rec.column(i).null_count == 0
+                                              else pa.array(np.nan_to_num(rec.column(i).to_numpy(zero_copy_only=False)).astype(rec.schema.field(i).type.to_pandas_dtype()))
+                                              for i in keep], names=[rec.schema.field(i).name for i in keep])
+            al = empty_aliases(num)
+            sql = f"{random_numeric(rng, 2, ['i8', 'i16', 'i32', 'small'])} {rng.choice(['<', '>=', '='])} {random_numeric(rng, 1, ['i32', 'small', 'f32'])}"
+            e = parse_expr(sql)
+            k = int(rng.integers(2, 9))
+            cut = sorted(set(int(x) for x in rng.integers(2, max(3, num.num_rows - 2), k))) if num.num_rows > 8 else []
+            parts = [num.slice(a, b - a) for a, b in zip([0] + cut, cut + [num.num_rows])]
+            ctx.set_option("group_mode", int(rng.integers(0, 3)))
+            ec, exp = outcome(lambda: [O.filter_record(p, al, e) for p in parts])
+            if rng.random() < 0.5:
+                gc, got = outcome(lambda: chq.filter_records(parts, al, e, ctx=ctx))
+                same = got is None or all(batches_identical(g, x) for g, x in zip(got, exp))
+            else:
+                devs = [chq.DeviceRecordBatch.from_host(p, ctx) for p in parts]
+                gc, got = outcome(lambda: chq.filter_records_coalesced(devs, al, e, ctx=ctx))
+                if got is not None:
+                    whole = pa.Table.from_batches(exp).combine_chunks()
+                    whole = whole.to_batches()[0] if whole.num_rows else exp[0].slice(0, 0)
+                    same = got[1] == [x.num_rows for x in exp] and batches_identical(got[0].to_host(), whole)
+                else:
+                    same = True
+            ctx.set_option("group_mode", 0)
+            kind = "group1"
         else:
             sql = random_predicate(rng, 2)
             e = parse_expr(sql)
