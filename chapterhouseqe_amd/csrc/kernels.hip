@@ -401,6 +401,13 @@ struct Interp {
         lo[j] = (uint32_t)w;
       }
     } else if (cls == C_F32) {
+      // +, * and / with a finite non-zero literal cannot be an invalid operation, and a NaN in the other operand is
+      // propagated (quieted) by the hardware exactly as SSE does: no fix-ups needed (`e / 3.0`, `x * 2.0`, `v + 10.0`)
+      bool nan_care = true;
+      if (bconst && op != OP_REM) {
+        const float c = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bl(0)));
+        nan_care = !(c == c && c != 0.0f && fabsf(c) != INFINITY);
+      }
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const float x = __uint_as_float(lo[j]), y = __uint_as_float(bl(j));
@@ -413,11 +420,13 @@ struct Interp {
         // an invalid operation on non-NaN inputs (0/0, inf + -inf, 0 * inf, fmod(x, 0)) yields the DEFAULT NaN, whose
         // sign is a property of the machine: the reference's hosts (x86-64 SSE) produce 0xFFC00000, gfx950 0x7FC00000.
         // arrow's comparisons are totalOrder, so the sign decides whether `nan < x` holds: follow the reference's host.
-        if (w != w && a == a && b == b) w = __uint_as_float(0xFFC00000u);
-        // NaN operands: SSE returns the first NaN operand, quieted (glibc's fmod reaches the same value through
-        // (x * y) / (x * y)); the GPU's fmod and a commuted hardware add / mul may pick the other one or a canonical NaN
-        if (a != a) w = __uint_as_float(__float_as_uint(a) | 0x00400000u);
-        else if (b != b) w = __uint_as_float(__float_as_uint(b) | 0x00400000u);
+        if (nan_care) {
+          if (w != w && a == a && b == b) w = __uint_as_float(0xFFC00000u);
+          // NaN operands: SSE returns the first NaN operand, quieted (glibc's fmod reaches the same value through
+          // (x * y) / (x * y)); the GPU's fmod and a commuted hardware add / mul may pick the other one or a canonical NaN
+          if (a != a) w = __uint_as_float(__float_as_uint(a) | 0x00400000u);
+          else if (b != b) w = __uint_as_float(__float_as_uint(b) | 0x00400000u);
+        }
         lo[j] = __float_as_uint(w);
       }
     } else if constexpr (WIDE) {

@@ -466,3 +466,12 @@ def test_default_nan_of_invalid_operations_matches_the_host(ctx):
         assert arrays_identical(got, exp, nan_payload=True), f"{sql}: {got.to_pylist()} vs {exp.to_pylist()}"
     for sql in ["x / y < 1.0", "x % y < 37.0 / x", "dx * dy >= dx", "x + y = x + y"]:
         assert check_same(ctx, rec, al, sql, "filter") == "ok", sql
+    # NaN operands of either sign and payload against literals (the literal paths skip the fix-ups when they cannot matter)
+    nans = np.frombuffer(np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0xFFA00123, 0x7FFFFFFF, 0x3F800000], dtype=np.uint32).tobytes(), dtype=np.float32)
+    rn = pa.RecordBatch.from_arrays([pa.array(nans), pa.array(nans[::-1].copy())], names=["x", "y"])
+    aln = empty_aliases(rn)
+    for sql in ["x / 3.0", "3.0 / x", "x * 2.0", "x + 10.0", "x % 3.0", "3.0 % x", "x / 0.0", "x * 0.0", "x + y", "x * y", "x / y", "x % y"]:
+        e = parse_expr(sql)
+        got = chq.compute_value(rn, aln, e, ctx=ctx)[0]
+        exp = O.compute_value(rn, aln, e)[0]
+        assert arrays_identical(got, exp, nan_payload=True), f"{sql}: {[hex(v) for v in np.frombuffer(got.buffers()[1], dtype=np.uint32)[:6]]} vs {[hex(v) for v in np.frombuffer(exp.buffers()[1], dtype=np.uint32)[:6]]}"
