@@ -20,6 +20,57 @@ from .test_gpu_parity import make_batch, random_numeric, random_predicate
 SIZES = [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 4100, 16383, 16384, 16385, 33000, 70001]
 
 
+TYPE_POOL = [pa.int8(), pa.int16(), pa.int32(), pa.int64(), pa.uint8(), pa.uint16(), pa.uint32(), pa.uint64(), pa.float32(),
+             pa.float64(), pa.bool_(), pa.utf8()]
+
+
+def random_schema_batch(rng, n):
+    """random column types / order / duplicate names / null masks + random table aliases"""
+    k = int(rng.integers(1, 9))
+    names, arrays, aliases = [], [], []
+    for i in range(k):
+        t = TYPE_POOL[int(rng.integers(0, len(TYPE_POOL)))]
+        name = str(rng.choice(["a", "b", "c", "d", "val", "a"]))
+        mask = (rng.random(n) < 0.15) if (n and rng.random() < 0.5) else None
+        if t == pa.utf8():
+            arr = pa.array(rng.choice(np.array(["", "x", "xy", "b", "long string " * 6]), n) if n else np.array([], dtype=object), type=t, mask=mask)
+        elif t == pa.bool_():
+            arr = pa.array(rng.integers(0, 2, n).astype(bool), mask=mask)
+        elif pa.types.is_floating(t):
+            vals = (rng.random(n) * 20 - 10)
+            if n:
+                vals[rng.integers(0, n, max(1, n // 50))] = rng.choice([0.0, -0.0, np.inf, -np.inf, np.nan])
+            arr = pa.array(vals.astype(t.to_pandas_dtype()), mask=mask)
+        else:
+            hi = min(100, np.iinfo(t.to_pandas_dtype()).max)
+            lo = -100 if np.iinfo(t.to_pandas_dtype()).min < 0 else 0
+            arr = pa.array(rng.integers(lo, hi, n).astype(t.to_pandas_dtype()), mask=mask)
+        names.append(name); arrays.append(arr)
+        aliases.append([] if rng.random() < 0.3 else [str(rng.choice(["t", "u"]))])
+    return pa.RecordBatch.from_arrays(arrays, names=names), aliases
+
+
+def random_ident(rng, names):
+    nm = str(rng.choice(names + ["nope"]))
+    r = rng.random()
+    if r < 0.6:
+        return nm
+    if r < 0.95:
+        return f"{rng.choice(['t', 'u', 'w'])}.{nm}"
+    return f"x.y.{nm}"
+
+
+def random_expr2(rng, names, depth):
+    if depth == 0 or rng.random() < 0.3:
+        r = rng.random()
+        if r < 0.7:
+            return random_ident(rng, names)
+        return str(rng.choice(["1", "2", "0", "2.5", "0.0", "3000000000", "'x'", "'b'", "true", "false"]))
+    op = str(rng.choice(["+", "*", "/", "%", "<", "<=", "=", "<>", ">", ">=", "and", "or"]))
+    e = f"{random_expr2(rng, names, depth - 1)} {op} {random_expr2(rng, names, depth - 1)}"
+    return f"({e})" if rng.random() < 0.6 else e
+
+
 def outcome(fn):
     try:
         return None, fn()
@@ -49,6 +100,59 @@ def main():
         al = empty_aliases(rec)
         ctx = ctxs[int(rng.integers(0, len(ctxs)))]
         mode = rng.random()
+        if rng.random() < 0.35:
+            # random schemas (types, order, duplicate names, nulls, NaN / inf / signed zeros) and table aliases
+            rec, al = random_schema_batch(rng, int(rng.choice([0, 1, 2, 5, 64, 65, 700, 2049, 20000])))
+            names = rec.schema.names
+            r = rng.random()
+            if r < 0.4:
+                sql = random_expr2(rng, names, int(rng.integers(1, 4)))
+                e = parse_expr(sql)
+                ec, exp = outcome(lambda: O.compute_value(rec, al, e))
+                gc, got = outcome(lambda: chq.compute_value(rec, al, e, ctx=ctx))
+                kind = "schema-value"
+                same = got is None or (got[1] == exp[1] and arrays_identical(got[0], exp[0], nan_payload=True))
+            elif r < 0.7:
+                sql = random_expr2(rng, names, int(rng.integers(1, 4)))
+                e = parse_expr(sql)
+                ec, exp = outcome(lambda: O.filter_record(rec, al, e))
+                gc, got = outcome(lambda: chq.filter_record(rec, al, e, ctx=ctx))
+                kind = "schema-filter"
+                same = got is None or batches_identical(got, exp, nan_payload=True)
+            else:
+                items = []
+                for _ in range(int(rng.integers(1, 5))):
+                    q = rng.random()
+                    if q < 0.15:
+                        items.append("*")
+                    elif q < 0.5:
+                        items.append(random_ident(rng, names))
+                    elif q < 0.8:
+                        items.append(random_expr2(rng, names, 2))
+                    else:
+                        items.append(random_expr2(rng, names, 2) + f" as out{len(items)}")
+                sql = "select " + ", ".join(items) + " from t"
+                sel = parse_select(sql)
+                ec, exp = outcome(lambda: O.project_record(sel.projection, rec, al))
+                gc, got = outcome(lambda: chq.project_record(sel.projection, rec, al, ctx=ctx))
+                kind = "schema-project"
+                same = got is None or batches_identical(got, exp, nan_payload=True)
+            stats[kind] = stats.get(kind, 0) + 1
+            if ec == 30 or gc == 30:
+                stats["unsupported"] += 1
+                if stats["unsupported"] <= 12:
+                    print(f"unsupported [{kind}] oracle {ec} gpu {gc}: {sql}   schema {[str(f.type) for f in rec.schema]}", flush=True)
+                continue
+            if ec is not None or gc is not None:
+                stats["errors"] += 1
+                if ec != gc:
+                    print(f"STATUS MISMATCH [{kind}] n={rec.num_rows}: oracle {ec}, gpu {gc}: {sql}\n schema {rec.schema} aliases {al}", flush=True)
+                    return 1
+                continue
+            if not same:
+                print(f"VALUE MISMATCH [{kind}] n={rec.num_rows}: {sql}\n schema {rec.schema} aliases {al}", flush=True)
+                return 1
+            continue
         if mode < 0.45:
             sql = random_predicate(rng, int(rng.integers(1, 4)))
             e = parse_expr(sql)
