@@ -129,3 +129,48 @@ def test_filtered_batch_moves_gpu_to_gpu_over_rccl():
             p.kill()
     msgs = dict(q.get(timeout=5) for _ in range(2))
     assert msgs.get("received") is True and msgs.get("sent", 0) > 0
+
+
+def test_steady_state_calls_do_not_grow_memory():
+    """the HBM / host pools recycle: after a warm-up round, thousands of calls of every kind leave the free HBM and the
+    process's resident set where they were"""
+    import gc
+    import resource
+    import torch
+    from chapterhouseqe_amd.sqlparse import parse_expr
+    from .test_gpu_group import fixed_batch
+    from .test_gpu_parity import make_batch
+    ctx = chq.Context(0)
+    sel = parse_select("select id, value1 + value2 as s from t where value2 > 10.0")
+    mixed = [make_batch(n, n) for n in (1000, 5000)]
+    plain = [fixed_batch(n, n, with_wide=False) for n in (1000, 10_000, 10_000, 3000)]
+    e_mixed, e_plain = parse_expr("f32 > 0.0 and s >= 'ab' or flag"), parse_expr("value2 > 10.0")
+
+    def one_round():
+        for rec in mixed:
+            al = [[] for _ in range(rec.num_columns)]
+            chq.filter_record(rec, al, e_mixed, ctx=ctx)
+            d = chq.DeviceRecordBatch.from_host(rec, ctx)
+            chq.filter_record(d, al, e_mixed, ctx=ctx).release()
+            chq.compute_value(rec, al, parse_expr("i32 * small + 1"), ctx=ctx)
+            d.release()
+        al = [[] for _ in range(plain[0].num_columns)]
+        chq.filter_records(plain, al, e_plain, ctx=ctx)
+        chq.filter_records_coalesced(plain, al, e_plain, ctx=ctx)
+        chq.filter_records(mixed[:1] * 3, [[] for _ in range(mixed[0].num_columns)], e_mixed, ctx=ctx)
+        chq.filter_project_record(sel.selection, sel.projection, plain[1], al, ctx=ctx)
+        chq.project_record(sel.projection, plain[1], al, ctx=ctx)
+
+    for _ in range(20):
+        one_round()
+    gc.collect(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for _ in range(300):
+        one_round()
+    gc.collect(); torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert free0 - free1 < 64 << 20, f"HBM in use grew by {(free0 - free1) >> 20} MiB over 300 rounds"
+    assert rss1 - rss0 < 256 << 10, f"peak RSS grew by {(rss1 - rss0) >> 10} MiB over 300 rounds"      # ru_maxrss is in KiB
+    ctx.close()
