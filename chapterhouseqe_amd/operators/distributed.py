@@ -214,3 +214,107 @@ def recv_device_record(src: int, ctx):
                 dist.recv(t, src)
                 tensors.append(t)
     return header["record_id"], tensors_to_device_record(header, tensors, ctx), header.get("table_aliases")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Exchange-level forwarding: the DAG puts a consumer (e.g. the single materialize instance) on another rank than some of
+# its producers (one filter instance per GPU).  A forwarder on the producer's rank drains the local exchange as the
+# consumer operator would (get_next_record -> ship -> operator_completed_record_processing, so the pool's ack and
+# garbage-collection rules are unchanged) and the receiving rank adds the records to its own exchange under their
+# original record ids.  Host batches travel with send_record, batches in HBM with send_device_record (RCCL over xGMI).
+# ---------------------------------------------------------------------------------------------------------------
+_END_OF_STREAM = -1
+
+
+def forward_exchange(ex, operator_id: str, instance_id: int, dst: int, device=None, poll_s: float = 0.002) -> int:
+    """Drain `ex` on behalf of consumer operator `operator_id` and ship every record to rank `dst`; returns the number of
+    records shipped.  Ends (after the exchange reports NONE_LEFT) with an end-of-stream marker."""
+    import time
+    from ..record_utils import DeviceRecordBatch
+    from .exchange_operator import NONE_AVAILABLE, NONE_LEFT
+    shipped = 0
+    device = _default_device(device)
+    while True:
+        got = ex.get_next_record(operator_id, instance_id)
+        if got == NONE_LEFT:
+            break
+        if got == NONE_AVAILABLE:
+            time.sleep(poll_s)
+            continue
+        record_id, record, aliases = got
+        if isinstance(record, DeviceRecordBatch):
+            _send_kind(1, dst, device)
+            send_device_record(record, record_id, dst, aliases)
+        else:
+            _send_kind(0, dst, device)
+            send_record(record, record_id, dst, device)
+            _send_json(aliases, dst, device)
+        ex.operator_completed_record_processing(operator_id, record_id)
+        shipped += 1
+    _send_kind(_END_OF_STREAM, dst, device)
+    return shipped
+
+
+def receive_into_exchange(ex, srcs: Sequence[int], ctx=None, device=None) -> int:
+    """Receive what `forward_exchange` ships from every rank in `srcs` (one after the other) and add it to `ex`; returns
+    the number of records added.  `ctx`: the chq context that will own received HBM batches."""
+    added = 0
+    device = _default_device(device)
+    for src in srcs:
+        while True:
+            kind = _recv_kind(src, device)
+            if kind == _END_OF_STREAM:
+                break
+            if kind == 1:
+                record_id, record, aliases = recv_device_record(src, ctx)
+            else:
+                record_id, record = recv_record(src, device)
+                aliases = _recv_json(src, device)
+            ex.send_record(record_id, record, aliases)
+            added += 1
+    return added
+
+
+def _default_device(device):
+    """control tensors must live where the backend can reach them: HBM for nccl (= RCCL), host memory for gloo"""
+    import torch
+    import torch.distributed as dist
+    if device is None and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def _send_kind(kind: int, dst: int, device) -> None:
+    import torch
+    import torch.distributed as dist
+    dist.send(torch.tensor([kind], dtype=torch.int64, device=device), dst)
+
+
+def _recv_kind(src: int, device) -> int:
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(t, src)
+    return int(t.item())
+
+
+def _send_json(obj, dst: int, device) -> None:
+    import torch
+    import torch.distributed as dist
+    blob = torch.frombuffer(bytearray(json.dumps(obj).encode()), dtype=torch.uint8)
+    blob = blob.to(device) if device is not None else blob
+    dist.send(torch.tensor([blob.numel()], dtype=torch.int64, device=device), dst)
+    if blob.numel():
+        dist.send(blob, dst)
+
+
+def _recv_json(src: int, device):
+    import torch
+    import torch.distributed as dist
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(n, src)
+    if int(n.item()) == 0:
+        return None
+    blob = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    dist.recv(blob, src)
+    return json.loads(blob.cpu().numpy().tobytes().decode())

@@ -102,11 +102,27 @@ def _p2p_worker(rank, port, q):
         if rank == 0:   # filter on GPU 0, ship the survivors to GPU 1 over xGMI
             out = chq.filter_record(chq.DeviceRecordBatch.from_host(rec, ctx), al, e, ctx=ctx)
             send_device_record(out, 7, 1, al)
-            q.put(("sent", out.num_rows))
+            # ... and a whole exchange of HBM-resident records, forwarded under their record ids
+            from chapterhouseqe_amd.operators import ExchangeOperator
+            from chapterhouseqe_amd.operators.distributed import forward_exchange
+            ex = ExchangeOperator("mid", ["consumer"])
+            for rid in range(3):
+                ex.send_record(rid, chq.filter_record(chq.DeviceRecordBatch.from_host(rec.slice(rid * 5000, 5000), ctx), al, e, ctx=ctx), al)
+            ex.producers_completed()
+            shipped = forward_exchange(ex, "consumer", 0, dst=1)
+            q.put(("sent", out.num_rows + shipped))
         else:
             rid, got, aliases = recv_device_record(0, ctx)
+            from chapterhouseqe_amd.operators import ExchangeOperator
+            from chapterhouseqe_amd.operators.distributed import receive_into_exchange
             from .helpers import batches_identical
             ok = rid == 7 and aliases == al and batches_identical(got.to_host(), O.filter_record(rec, al, e))
+            ex = ExchangeOperator("mid_on_rank1", ["consumer"])
+            ok = ok and receive_into_exchange(ex, [0], ctx=ctx) == 3
+            for _ in range(3):
+                rid2, r2, al2 = ex.get_next_record("consumer", 0)
+                ok = ok and isinstance(r2, chq.DeviceRecordBatch) and al2 == al and \
+                    batches_identical(r2.to_host(), O.filter_record(rec.slice(rid2 * 5000, 5000), al, e))
             q.put(("received", bool(ok)))
         dist.barrier()
     finally:

@@ -195,6 +195,68 @@ def test_two_instances_over_gloo(tmp_path):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def _dag_worker(rank, world, port, tmpdir):
+    """[read_files] -> [exchange] -> [filter, one instance per rank] -> [exchange] --forward--> rank 0: [materialize]"""
+    import torch.distributed as dist
+    from chapterhouseqe_amd.operators.distributed import forward_exchange, receive_into_exchange
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        batches = simple_batches(3000, 8, 100, seed=9)
+        sql = "select id, value1, (value2 + 10) / 100 as v from read_files('x') where id % 3 = 0"
+        sel = parse_select(sql)
+        ex_in = ExchangeOperator("operator_p0_exchange", ["operator_p1_producer"])
+        ex_mid = ExchangeOperator("operator_p1_exchange", ["operator_p2_producer"])
+        for rid in shard_record_ids(range(len(batches)), rank, world):      # this rank's share of the table function's output
+            ex_in.send_record(rid, batches[rid], [[] for _ in range(batches[rid].num_columns)])
+        ex_in.producers_completed()
+        ftask = FilterOperatorTask(sel.selection)
+        run = FilterTaskBuilder(O.filter_record).build(OperatorInstanceConfig(rank + 1, "operator_p1_producer", 42, ftask), [ex_in], ex_mid)
+        assert run() is None
+        ex_mid.producers_completed()
+        if rank != 0:
+            shipped = forward_exchange(ex_mid, "operator_p2_producer", 100 + rank, dst=0)
+            assert shipped == len(shard_record_ids(range(len(batches)), rank, world)) and ex_mid.num_records() == 0
+        else:
+            # the consumer's exchange on rank 0 takes the local filter's output (already there) and everyone else's
+            ex_all = ExchangeOperator("operator_p1_exchange_rank0", ["operator_p2_producer"])
+            while True:
+                got = ex_mid.get_next_record("operator_p2_producer", 0)
+                if not isinstance(got, tuple):
+                    break
+                ex_all.send_record(*got)
+                ex_mid.operator_completed_record_processing("operator_p2_producer", got[0])
+            added = receive_into_exchange(ex_all, [r for r in range(world) if r != 0])
+            assert added == len(batches) - len(shard_record_ids(range(len(batches)), 0, world))
+            ex_all.producers_completed()
+            mtask = MaterializeFilesOperatorTask("parquet", sel.projection)
+            reg = OperatorTaskRegistry().add_materialize_files_builder(MaterializeFilesTaskBuilder(tmpdir, O.project_record), ["parquet"])
+            mrun = reg.find_task_builder(mtask).build(OperatorInstanceConfig(99, "operator_p2_producer", 42, mtask), [ex_all], None)
+            assert mrun() is None and ex_all.num_records() == 0
+            d = os.path.dirname(mrun.task.files_written[0])
+            for rid, b in enumerate(batches):                                   # one file per record id, whichever rank filtered it
+                al = [[] for _ in range(b.num_columns)]
+                exp = O.project_record(sel.projection, O.filter_record(b, al, sel.selection), al)
+                got = pq.read_table(os.path.join(d, f"rec_{rid}.parquet")).to_batches()
+                got = got[0] if got else exp.slice(0, 0)
+                assert got.to_pydict() == exp.to_pydict(), rid
+        dist.barrier()
+        open(os.path.join(tmpdir, f"dag_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_filter_instances_on_two_ranks_feed_one_materialize_over_gloo(tmp_path):
+    """the multi-GPU DAG of SURVEY 8e with host batches on the CPU backend: one filter instance per rank, the single
+    materialize instance on rank 0, records forwarded rank to rank under their record ids"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dag_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "dag_ok0") and os.path.exists(tmp_path / "dag_ok1")
+
+
 def test_shard_record_ids_partitions():
     ids = list(range(23))
     parts = [shard_record_ids(ids, r, 4) for r in range(4)]
