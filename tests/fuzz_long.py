@@ -225,9 +225,19 @@ def main():
             cut = sorted(set(int(x) for x in rng.integers(0, max(1, rec.num_rows), k)))
             parts = [rec.slice(a, b - a) for a, b in zip([0] + cut, cut + [rec.num_rows])]
             ec, exp = outcome(lambda: [O.filter_record(p, al, e) for p in parts])
-            gc, got = outcome(lambda: chq.filter_records(parts, al, e, ctx=ctx))
             kind = "group"
-            same = got is None or all(batches_identical(g, x) for g, x in zip(got, exp))
+            if rng.random() < 0.6:
+                gc, got = outcome(lambda: chq.filter_records(parts, al, e, ctx=ctx))
+                same = got is None or all(batches_identical(g, x) for g, x in zip(got, exp))
+            else:   # joined output (general column kinds: concatenated on the host) from host or device batches
+                src = [chq.DeviceRecordBatch.from_host(p, ctx) for p in parts] if rng.random() < 0.4 else parts
+                gc, got = outcome(lambda: chq.filter_records_coalesced(src, al, e, ctx=ctx))
+                same = True
+                if got is not None:
+                    whole = pa.Table.from_batches(exp).combine_chunks()
+                    whole = whole.to_batches()[0] if whole.num_rows else exp[0].slice(0, 0)
+                    joined = got[0].to_host() if hasattr(got[0], "to_host") else got[0]
+                    same = got[1] == [x.num_rows for x in exp] and batches_identical(joined, whole, check_nullable=False)
         stats[kind] += 1
         if ec == 30 or gc == 30:
             stats["unsupported"] += 1
