@@ -110,6 +110,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
     else if (k == "stash") ctx->c.opt_stash = value != 0;
+    else if (k == "small_host") ctx->c.opt_small_host = value != 0;
     else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
     else if (k == "split_rows") ctx->c.opt_split_rows = value;
@@ -166,6 +167,13 @@ chq_status chq_filter_record(chq_ctx* ctx, const ArrowDeviceArray* rec, const Ar
     require(expr, "expression"); require(out, "output array"); require(out_schema, "output schema");
     check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
     Batch in = import_batch(rec, schema);
+    if (out_device == ARROW_DEVICE_CPU && !in.on_device) {   // the reference's calling pattern: small host batch in, host batch out
+      Batch small;
+      if (filter_record_small_host(ctx->c, in, table_aliases, expr->e, &small)) {
+        export_batch(std::move(small), ARROW_DEVICE_CPU, out, out_schema);
+        return;
+      }
+    }
     Batch dev = to_device(ctx->c, in);
     auto pcols = plan_columns(dev, table_aliases);
     Batch res = filter_record(ctx->c, dev, pcols, expr->e);

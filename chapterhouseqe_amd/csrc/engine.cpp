@@ -114,6 +114,7 @@ Context::~Context() {
   if (ev1) (void)hipEventDestroy(ev1);
   if (pinned) (void)hipHostFree(pinned);
   if (pinned_tbl) (void)hipHostFree(pinned_tbl);
+  if (pinned_io) (void)hipHostFree(pinned_io);
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -850,6 +851,113 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   }
   for (Column& o : out.cols) o.length = total;
   return out;
+}
+
+// =================================================================================================
+// filter_record_small_host: the reference's own calling pattern -- one 10 000-row host batch in, one host batch out --
+// costs three pageable uploads, three pageable downloads (each of them synchronous) and two stream synchronisations on
+// the general path: about 100 us, i.e. no faster than the CPU.  Here the columns are packed into ONE pinned block,
+// uploaded with one asynchronous copy, the outputs are written into one device block at input capacity and come back
+// with one asynchronous copy together with the row count: one synchronisation per call.
+// =================================================================================================
+bool filter_record_small_host(Context& ctx, const Batch& rec, const chq_table_aliases* aliases, const Expr& expr, Batch* result) {
+  const int64_t nrows = rec.nrows;
+  const size_t ncols = rec.cols.size();
+  if (!ctx.opt_small_host || rec.on_device || nrows < 2 || nrows > (1 << 18) || ncols == 0 || (int)ncols > MAX_OUT) return false;
+  constexpr size_t kAlign = 256;
+  std::vector<size_t> at(ncols + 1, 0);
+  for (size_t i = 0; i < ncols; ++i) {
+    const Column& c = rec.cols[i];
+    if (c.type == T_BOOL || c.type == T_UTF8 || c.width <= 0) return false;
+    if (c.validity && c.null_count != 0 && (c.null_count > 0 || count_nulls_host(c.validity, c.offset, c.length) != 0)) return false;
+    at[i + 1] = at[i] + ((size_t)nrows * c.width + kAlign - 1) / kAlign * kAlign;
+  }
+  const size_t block = at[ncols];
+  if (block > ((size_t)8 << 20)) return false;
+  const std::vector<PlanColumn> pcols = plan_columns(rec, aliases);
+  Lowered lw;
+  try {
+    TypedExpr te = type_expr(expr, pcols, nrows, ctx.opt_enable_minus);
+    if (te.pending_code) return false;
+    const Node& root = te.at(te.root);
+    if (root.type != T_BOOL || root.len1) return false;
+    lower_expr(te, te.root, pcols, lw);
+  } catch (const ChqError&) {
+    return false;   // the general path reports it
+  }
+  if (!lw.strs.empty()) return false;
+
+  if (ctx.pinned_io_bytes < 2 * block + 64) {
+    if (ctx.pinned_io) (void)hipHostFree(ctx.pinned_io);
+    ctx.pinned_io = nullptr; ctx.pinned_io_bytes = 0;
+    const size_t cap = std::max<size_t>(2 * block + 64, (size_t)1 << 20);
+    check_hip(hipHostMalloc(&ctx.pinned_io, cap, hipHostMallocDefault), "hipHostMalloc (small host path)");
+    ctx.pinned_io_bytes = cap;
+    ctx.dev_io = make_device_buffer(cap, ctx.device);
+  }
+  uint8_t* h_in = (uint8_t*)ctx.pinned_io; uint8_t* h_out = h_in + block;
+  uint8_t* d_in = (uint8_t*)ctx.dev_io->ptr; uint8_t* d_out = d_in + block;
+  for (size_t i = 0; i < ncols; ++i) memcpy(h_in + at[i], rec.cols[i].values0(), (size_t)nrows * rec.cols[i].width);
+  check_hip(hipMemcpyAsync(d_in, h_in, block, hipMemcpyHostToDevice, ctx.stream), "upload packed batch");
+
+  const int tile_kind = (lw.wide || lw.num_temps > 0) ? 2 : 1;
+  const int64_t tile_rows = kTileRows[tile_kind];
+  const int64_t ntiles = (nrows + tile_rows - 1) / tile_rows;
+  ensure_scratch(ctx, ntiles);
+  Scratch* ds = dev_scratch(ctx);
+  Scratch* hs = (Scratch*)ctx.pinned;
+
+  // a view of the batch whose columns live in the device block (what the program's column refs resolve against)
+  Batch dev;
+  dev.nrows = nrows; dev.on_device = true; dev.device_id = ctx.device;
+  for (size_t i = 0; i < ncols; ++i) {
+    Column c = empty_like(rec.cols[i]);
+    c.length = nrows; c.values = d_in + at[i];
+    dev.cols.push_back(std::move(c));
+  }
+  FilterParams p{};
+  p.nrows = nrows; p.tile_begin = 0; p.tile_end = ntiles;
+  p.status = dev_status(ctx); p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
+  fill_refs(p.pb, lw, dev, {});
+  std::vector<int> launch_cols;
+  for (size_t i = 0; i < ncols; ++i) launch_cols.push_back((int)i);
+  p.stash_ref = -1;
+  if (ctx.opt_stash) {
+    for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
+      if (rec.cols[lw.refs[r]].width > 4) continue;
+      auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
+      if (it != launch_cols.end()) { launch_cols.erase(it); launch_cols.push_back(lw.refs[r]); p.stash_ref = (int16_t)r; }
+    }
+  }
+  int n = 0;
+  for (int ci : launch_cols) {
+    p.outs[n].in = d_in + at[ci]; p.outs[n].out = d_out + at[ci]; p.outs[n].width = (uint32_t)rec.cols[ci].width;
+    ++n;
+  }
+  p.n_out = (int16_t)n;
+  ctx.stats = chq_call_stats{};
+  ctx.stats.rows_in = nrows; ctx.stats.tiles = ntiles; ctx.stats.launches = 1;
+  check_hip(hipMemsetAsync(ds, 0, kHeader + (size_t)(ntiles + 1) * 8, ctx.stream), "memset scratch + status");
+  const int grid_cap = ctx.num_cus * kGridPerCu[tile_kind];
+  check_hip(launch_filter(p, tile_kind, true, (int)std::min<int64_t>(ntiles, grid_cap), ctx.stream), "launch filter_fused_kernel (small host batch)");
+  check_hip(hipMemcpyAsync(h_out, d_out, block, hipMemcpyDeviceToHost, ctx.stream), "download packed result");
+  check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  if (hs->err != ERR_NONE) return false;   // the general path reports the error
+  const int64_t total = (int64_t)hs->total;
+  Batch out;
+  out.on_device = false; out.device_id = -1; out.nrows = total;
+  for (size_t i = 0; i < ncols; ++i) {
+    Column o = empty_like(rec.cols[i]);
+    auto hb = make_host_buffer((size_t)total * o.width + 16);
+    if (total) memcpy(hb->ptr, h_out + at[i], (size_t)total * o.width);
+    o.values = (const uint8_t*)hb->ptr; o.length = total; o.owned.push_back(hb);
+    ctx.stats.bytes_read_alg += nrows * o.width; ctx.stats.bytes_written_alg += total * o.width;
+    out.cols.push_back(std::move(o));
+  }
+  ctx.stats.rows_out = total;
+  *result = std::move(out);
+  return true;
 }
 
 // =================================================================================================

@@ -130,6 +130,10 @@ struct Context {
   size_t pinned_bytes = 0;
   void* pinned_tbl = nullptr;              // pinned staging of a batch-group launch (tile table, per-batch prefixes)
   size_t pinned_tbl_bytes = 0;
+  void* pinned_io = nullptr;               // pinned staging of the small host-batch path: [inputs | outputs]
+  size_t pinned_io_bytes = 0;
+  BufferPtr dev_io;                        // its device twin
+  bool opt_small_host = true;              // host batches up to a few MB: one upload, one download, one synchronisation
 
   ~Context();
 };
@@ -150,6 +154,9 @@ Batch to_host(Context& ctx, const Batch& b);
 struct SplitRequest { std::vector<int64_t> starts; std::vector<int64_t> bounds; };
 Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr,
                     SplitRequest* split = nullptr);
+// A small host batch, host result: columns staged through one pinned block each way (one H2D, one D2H, one stream
+// synchronisation).  False = outside its scope or an error was flagged: take the general path.
+bool filter_record_small_host(Context& ctx, const Batch& rec_host, const chq_table_aliases* aliases, const Expr& expr, Batch* result);
 // one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
                                   const Expr& expr, bool out_on_device);

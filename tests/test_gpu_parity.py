@@ -475,3 +475,37 @@ def test_default_nan_of_invalid_operations_matches_the_host(ctx):
         got = chq.compute_value(rn, aln, e, ctx=ctx)[0]
         exp = O.compute_value(rn, aln, e)[0]
         assert arrays_identical(got, exp, nan_payload=True), f"{sql}: {[hex(v) for v in np.frombuffer(got.buffers()[1], dtype=np.uint32)[:6]]} vs {[hex(v) for v in np.frombuffer(exp.buffers()[1], dtype=np.uint32)[:6]]}"
+
+
+@pytest.mark.parametrize("n", [2, 65, 2049, 10_000, 100_000, 262_144, 262_145])
+def test_small_host_batches_take_the_single_sync_path(ctx, n):
+    """the reference's calling pattern: a fixed-width host batch in, a host batch out -- staged through one pinned block
+    each way (engine.cpp:filter_record_small_host); identical results with the path switched off"""
+    rng = np.random.default_rng(n)
+    rec = pa.RecordBatch.from_arrays(
+        [pa.array(np.arange(n, dtype=np.int32)), pa.array((rng.random(n) * 100).astype(np.float32)),
+         pa.array(rng.integers(-100, 100, n).astype(np.int8)), pa.array(rng.random(n) * 10),
+         pa.array(rng.integers(0, 2**40, n).astype(np.int64)), pa.array(rng.integers(0, 60000, n).astype(np.uint16))],
+        names=["id", "v", "b", "d", "l", "h"])
+    al = empty_aliases(rec)
+    off = chq.Context(0)
+    off.set_option("small_host", 0)
+    for sql in ["v > 10.0", "id % 2 = 0 and b < 0", "d * 2.0 > 5.0 or l % 3 = 0", "h > 70000", "id = id", "b + id > 100 and v < 50.0"]:
+        e = parse_expr(sql)
+        exp = O.filter_record(rec, al, e)
+        got = chq.filter_record(rec, al, e, ctx=ctx)
+        st = ctx.last_stats()
+        assert batches_identical(got, exp), f"{sql} (n={n}):\n{explain_diff(got, exp)}"
+        assert st["rows_in"] == n and st["rows_out"] == exp.num_rows
+        if n <= 262_144:
+            assert st["launches"] == 1
+        assert batches_identical(chq.filter_record(rec, al, e, ctx=off), exp)
+    # data-dependent errors are the general path's to report, unchanged
+    for sql, code in [("id * 100000 > 0", 20 if n > 21475 else None), ("v > 1.0 and 10 / (id % 2) > 1", 21)]:
+        if code is None:
+            continue
+        with pytest.raises(chq.ChqError) as ei:
+            chq.filter_record(rec, al, parse_expr(sql), ctx=ctx)
+        assert ei.value.code == code, sql
+    assert check_same(ctx, rec, al, "nope > 1", "filter") == "error"
+    off.close()
