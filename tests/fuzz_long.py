@@ -203,8 +203,16 @@ def main():
             cut = sorted(set(int(x) for x in rng.integers(2, max(3, num.num_rows - 2), k))) if num.num_rows > 8 else []
             parts = [num.slice(a, b - a) for a, b in zip([0] + cut, cut + [num.num_rows])]
             ctx.set_option("group_mode", int(rng.integers(0, 3)))
-            ec, exp = outcome(lambda: [O.filter_record(p, al, e) for p in parts])
-            if rng.random() < 0.5:
+            if rng.random() < 0.3:   # one fixed-width host batch in, host batch out: the single-synchronisation path
+                ec, exp = outcome(lambda: O.filter_record(num, al, e))
+                gc, got = outcome(lambda: chq.filter_record(num, al, e, ctx=ctx))
+                same = got is None or batches_identical(got, exp)
+                parts = None
+            else:
+                ec, exp = outcome(lambda: [O.filter_record(p, al, e) for p in parts])
+            if parts is None:
+                pass
+            elif rng.random() < 0.5:
                 gc, got = outcome(lambda: chq.filter_records(parts, al, e, ctx=ctx))
                 same = got is None or all(batches_identical(g, x) for g, x in zip(got, exp))
             else:
