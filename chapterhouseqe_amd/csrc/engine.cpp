@@ -1810,7 +1810,8 @@ bool filter_project_fused(Context& ctx, const Batch& rec, const std::vector<Plan
   int n_copy = 0;
   for (const Item& it : items) n_copy += it.copy_col >= 0;
   if (n_copy > MAX_FUSED_COPY) return false;
-  if (ctx.opt_fuse == 1) {
+  if (ctx.opt_fuse == 1 && nrows > (1 << 18)) {
+    // (small batches are latency-bound: one launch and one synchronisation always beat two of each)
     // Worth it?  The single pass is instruction-bound (interpreter + compacting stores in one kernel) while the two
     // steps run near the HBM roofline, so it only pays when it moves clearly fewer bytes: the filter step copies the
     // WHOLE table, the single pass touches only what the predicate and the select items need.  Selectivity is not

@@ -156,7 +156,7 @@ def test_calls_outside_the_fused_scope_take_the_two_steps(ctx):
 
 def test_default_picks_the_single_pass_only_when_it_moves_fewer_bytes():
     c = chq.Context(0)
-    rec = fixed_batch(40_000, 77, with_wide=True)     # 7 columns, 31 bytes per row
+    rec = fixed_batch(400_000, 77, with_wide=True)    # 7 columns, 31 bytes per row (small batches always take the single pass)
     run_fused(c, rec, "select value1 + value2 as s from t where id > 0", expect_fused=True)      # 3 of 7 columns touched
     st = run_fused(c, rec, "select *, id + 1 as n from t where id > 0", expect_fused=None)      # everything copied anyway
     assert st["launches"] >= 2
