@@ -259,9 +259,16 @@ chq_status chq_project_record(chq_ctx* ctx, const chq_select_item* fields, int n
     if (n_fields > 0) require(fields, "select items");
     check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
     Batch in = import_batch(rec, schema);
+    std::vector<chq_select_item> items(fields, fields + (n_fields > 0 ? n_fields : 0));
+    if (out_device == ARROW_DEVICE_CPU && !in.on_device) {   // the materialize task's calling pattern: host in, host out
+      Batch res_host;
+      if (project_record_host(ctx->c, items, in, table_aliases, &res_host)) {
+        export_batch(std::move(res_host), ARROW_DEVICE_CPU, out, out_schema);
+        return;
+      }
+    }
     Batch dev = to_device(ctx->c, in);
     auto pcols = plan_columns(dev, table_aliases);
-    std::vector<chq_select_item> items(fields, fields + (n_fields > 0 ? n_fields : 0));
     Batch res = project_record(ctx->c, items, dev, pcols);
     finish(ctx->c, std::move(res), out_device, out, out_schema);
   });

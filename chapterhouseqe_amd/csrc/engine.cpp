@@ -307,9 +307,10 @@ BitRange bit_range(int64_t offset, int64_t len) {
   int64_t fb = offset >> 3, lb = (offset + len + 7) >> 3;
   return {fb, lb - fb};
 }
-enum class Dir { H2D, D2H, D2D };
+enum class Dir { H2D, D2H, D2D, H2H };
 BufferPtr copy_bytes(Context& ctx, const uint8_t* src, int64_t nbytes, Dir dir, size_t pad = 16) {
-  BufferPtr out = dir == Dir::D2H ? make_host_buffer((size_t)nbytes + pad) : make_device_buffer((size_t)nbytes + pad, ctx.device);
+  BufferPtr out = (dir == Dir::D2H || dir == Dir::H2H) ? make_host_buffer((size_t)nbytes + pad) : make_device_buffer((size_t)nbytes + pad, ctx.device);
+  if (dir == Dir::H2H) { if (nbytes > 0) memcpy(out->ptr, src, (size_t)nbytes); return out; }
   if (nbytes > 0) {
     hipMemcpyKind k = dir == Dir::H2D ? hipMemcpyHostToDevice : (dir == Dir::D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
     check_hip(hipMemcpyAsync(out->ptr, src, (size_t)nbytes, k, ctx.stream), "hipMemcpyAsync");
@@ -338,7 +339,7 @@ Column copy_column(Context& ctx, const Column& c, Dir dir) {
     // offsets [base, offset+n]; data bytes [off[offset], off[offset+n]) -- need the two end offsets on the host
     int32_t ends[2] = {0, 0};
     if (c.values) {
-      if (dir == Dir::H2D) { const int32_t* offs = (const int32_t*)c.values; ends[0] = offs[c.offset]; ends[1] = offs[c.offset + n]; }
+      if (dir == Dir::H2D || dir == Dir::H2H) { const int32_t* offs = (const int32_t*)c.values; ends[0] = offs[c.offset]; ends[1] = offs[c.offset + n]; }
       else {
         check_hip(hipMemcpyAsync(&ends[0], c.values + 4 * c.offset, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
         check_hip(hipMemcpyAsync(&ends[1], c.values + 4 * (c.offset + n), 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
@@ -348,7 +349,7 @@ Column copy_column(Context& ctx, const Column& c, Dir dir) {
     auto ob = c.values ? copy_bytes(ctx, c.values + 4 * base, 4 * (n + phase + 1), dir) : copy_bytes(ctx, nullptr, 0, dir);
     if (!c.values) {   // empty array without an offsets buffer: synthesise [0]
       int32_t zero[9] = {0};
-      if (dir == Dir::D2H) memcpy(ob->ptr, zero, sizeof zero); else check_hip(hipMemcpy(ob->ptr, zero, 16, hipMemcpyHostToDevice), "memcpy");
+      if (dir == Dir::D2H || dir == Dir::H2H) memcpy(ob->ptr, zero, sizeof zero); else check_hip(hipMemcpy(ob->ptr, zero, 16, hipMemcpyHostToDevice), "memcpy");
     }
     o.values = (const uint8_t*)ob->ptr; o.owned.push_back(ob);
     const int64_t nb = (int64_t)ends[1] - ends[0];
@@ -1894,6 +1895,89 @@ bool filter_project_fused(Context& ctx, const Batch& rec, const std::vector<Plan
   out.nrows = total;
   ctx.stats.rows_out = total; ctx.stats.tiles = ntiles; ctx.stats.launches = 1;
   ctx.stats.bytes_written_alg = total * out_width;
+  *result = std::move(out);
+  return true;
+}
+
+// =================================================================================================
+// project_record_host: project_record for a HOST batch with a host result (the materialize task's calling pattern,
+// materialize_files_task.rs:110).  Only the columns the computed select items read are uploaded and only the computed
+// columns come back; identifier and wildcard items -- columns handed through unchanged, often the wide Utf8 ones --
+// are copied host to host and never cross PCIe.  False = outside its scope (an item fails typing, literal-only items,
+// QualifiedWildcard ...): the general path decides, in the reference's order.
+// =================================================================================================
+bool project_record_host(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec,
+                         const chq_table_aliases* aliases, Batch* result) {
+  if (rec.on_device || fields.empty()) return false;
+  const int64_t nrows = rec.nrows;
+  Batch host = rec;   // shallow: null counts resolved below
+  for (Column& c : host.cols) if (c.validity && c.null_count < 0) c.null_count = count_nulls_host(c.validity, c.offset, c.length);
+  const std::vector<PlanColumn> pcols = plan_columns(host, aliases);
+  struct Item { int copy_col; int computed; std::string name; bool keep_schema_flag; };
+  std::vector<Item> items;
+  std::vector<TypedExpr> computed;
+  try {
+    size_t unnamed_idx = 0;
+    for (const chq_select_item& f : fields) {
+      if (f.kind == CHQ_ITEM_WILDCARD) {
+        for (size_t ci = 0; ci < host.cols.size(); ++ci) items.push_back(Item{(int)ci, -1, host.cols[ci].name, true});
+        continue;
+      }
+      if ((f.kind != CHQ_ITEM_UNNAMED_EXPR && f.kind != CHQ_ITEM_EXPR_WITH_ALIAS) || !f.expr) return false;
+      const Expr& e = *(const Expr*)f.expr;
+      TypedExpr te = type_expr(e, pcols, nrows, ctx.opt_enable_minus);
+      if (te.pending_code) return false;
+      const Node& root = te.at(te.root);
+      if (root.len1) return false;
+      std::string name;
+      if (f.kind == CHQ_ITEM_EXPR_WITH_ALIAS) name = f.alias ? f.alias : "";
+      else if (e.kind == Expr::IDENT) name = e.text;                 // RU/record_projection.rs:41-48
+      else name = "unnamed_" + std::to_string(unnamed_idx);          // :49-53
+      if (f.kind == CHQ_ITEM_UNNAMED_EXPR) ++unnamed_idx;           // :58, counts identifiers too
+      if (root.kind == Node::COL) { items.push_back(Item{root.col, -1, name, false}); continue; }
+      items.push_back(Item{-1, (int)computed.size(), name, false});
+      computed.push_back(std::move(te));
+    }
+  } catch (const ChqError&) {
+    return false;
+  }
+  for (const Item& it : items)   // RecordBatch::try_new would refuse: let the general path say so
+    if (it.copy_col >= 0 && it.keep_schema_flag && !host.cols[it.copy_col].nullable && host.cols[it.copy_col].null_count > 0) return false;
+
+  ctx.stats = chq_call_stats{};
+  ctx.stats.rows_in = nrows; ctx.stats.rows_out = nrows;
+  std::vector<Column> results;
+  if (!computed.empty()) {
+    std::vector<char> needed(host.cols.size(), 0);
+    for (const TypedExpr& te : computed) for (const Node& n : te.nodes) if (n.kind == Node::COL) needed[n.col] = 1;
+    Batch dev;
+    dev.nrows = nrows; dev.on_device = true; dev.device_id = ctx.device;
+    for (size_t ci = 0; ci < host.cols.size(); ++ci) {
+      if (needed[ci]) dev.cols.push_back(copy_column(ctx, host.cols[ci], Dir::H2D));
+      else { Column ph = empty_like(host.cols[ci]); ph.length = nrows; dev.cols.push_back(std::move(ph)); }   // never dereferenced
+    }
+    std::vector<const TypedExpr*> ptrs;
+    for (const TypedExpr& te : computed) ptrs.push_back(&te);
+    std::vector<Column> dcols = evaluate_dense(ctx, dev, pcols, ptrs);
+    for (Column& c : dcols) results.push_back(copy_column(ctx, c, Dir::D2H));
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  }
+  Batch out;
+  out.on_device = false; out.device_id = -1; out.nrows = nrows;
+  for (const Item& it : items) {
+    Column c;
+    if (it.copy_col >= 0) {
+      c = copy_column(ctx, host.cols[it.copy_col], Dir::H2H);
+      c.nullable = it.keep_schema_flag ? host.cols[it.copy_col].nullable : c.null_count > 0;
+      if (c.validity && c.null_count == 0) c.validity = nullptr;
+    } else {
+      c = std::move(results[(size_t)it.computed]);
+      c.nullable = c.null_count > 0;
+    }
+    c.name = it.name;
+    out.cols.push_back(std::move(c));
+  }
+  if (out.cols.empty()) return false;
   *result = std::move(out);
   return true;
 }

@@ -168,6 +168,9 @@ Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, c
 // filter_record + project_record in one kernel pass; false = outside its scope (or an error was flagged): run the two steps
 bool filter_project_fused(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& pred,
                           const std::vector<chq_select_item>& fields, Batch* result);
+// project_record for a host batch with a host result: pass-through columns never cross PCIe; false = general path
+bool project_record_host(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_host,
+                         const chq_table_aliases* aliases, Batch* result);
 Column compute_value(Context& ctx, const Batch& rec_dev, const std::vector<PlanColumn>& pcols, const Expr& expr,
                      bool* is_scalar);
 
