@@ -500,6 +500,11 @@ def test_small_host_batches_take_the_single_sync_path(ctx, n):
         if n <= 262_144:
             assert st["launches"] == 1
         assert batches_identical(chq.filter_record(rec, al, e, ctx=off), exp)
+    if n > 10:   # Arrow slices (non-zero offsets) of host arrays go through the same path
+        sl = rec.slice(3, n - 5)
+        e = parse_expr("v > 10.0 and id % 2 = 0")
+        got = chq.filter_record(sl, al, e, ctx=ctx)
+        assert batches_identical(got, O.filter_record(sl, al, e)), n
     # data-dependent errors are the general path's to report, unchanged
     for sql, code in [("id * 100000 > 0", 20 if n > 21475 else None), ("v > 1.0 and 10 / (id % 2) > 1", 21)]:
         if code is None:
