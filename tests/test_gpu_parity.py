@@ -514,3 +514,12 @@ def test_small_host_batches_take_the_single_sync_path(ctx, n):
         assert ei.value.code == code, sql
     assert check_same(ctx, rec, al, "nope > 1", "filter") == "error"
     off.close()
+
+
+def test_a_short_run_of_the_long_fuzz(monkeypatch):
+    """tests/fuzz_long.py (random predicates, values, projections, groups, schemas; GPU vs oracle, strict NaN bits) for a
+    few seconds with a fixed seed -- the long runs are recorded in profiles/r1/fuzz_long.txt"""
+    import sys
+    from . import fuzz_long
+    monkeypatch.setattr(sys, "argv", ["fuzz_long", "8", "123"])
+    assert fuzz_long.main() == 0
