@@ -440,6 +440,11 @@ static uint8_t* union_validity(const datum* l, const datum* r, int64_t n, int64_
 }
 
 enum { AR_ADD, AR_SUB, AR_MUL, AR_DIV, AR_REM };
+/* Extension switch (default off = the reference's behaviour): BinaryOperator::Minus evaluates as arrow-arith
+ * numeric::sub instead of returning BinaryOperatorNotImplemented.  Exists only so the tests can check the product's
+ * opt-in "enable_minus" option (DEV_NOTES.md:54) against something. */
+static int g_extension_minus = 0;
+void oc_set_extension_minus(int on) { g_extension_minus = on != 0; }
 static const char* AR_SYM[] = {"+", "-", "*", "/", "%"};
 
 #define INT_ARITH(T, WIDE, TMIN, TMAX, IS_SIGNED)                                                            \
@@ -596,6 +601,12 @@ static int compute_value_rec(const oc_batch* rec, const oc_expr* e, datum* out, 
       }
       int arith = -1, cmp = -1;
       switch (e->op) {
+        case OC_OP_MINUS:
+          /* NOT the reference: it has no Minus arm (compute_value.rs:210-216). Only with oc_set_extension_minus(1), to
+           * check the product's opt-in `enable_minus` option: arrow-arith numeric::sub (checked ints, IEEE floats). */
+          if (g_extension_minus) { arith = AR_SUB; break; }
+          datum_free(&l); datum_free(&r);
+          return fail(err, errlen, OC_ERR_BINARY_OPERATOR_NOT_IMPLEMENTED, "binary operator not implemented: %s", e->text);
         case OC_OP_PLUS: arith = AR_ADD; break; case OC_OP_DIVIDE: arith = AR_DIV; break;
         case OC_OP_MULTIPLY: arith = AR_MUL; break; case OC_OP_MODULO: arith = AR_REM; break;
         case OC_OP_EQ: cmp = CM_EQ; break; case OC_OP_NOTEQ: cmp = CM_NE; break; case OC_OP_GT: cmp = CM_GT; break;

@@ -127,6 +127,12 @@ int oc_filter_project_table_batched(const oc_batch* rec, const oc_expr* pred,
                                     const oc_select_item* items, int nitems, int64_t batch_rows,
                                     int64_t* rows_out, double* seconds, char* err, int errlen);
 
+/* NON-REFERENCE extension switch, default 0.  The reference rejects BinaryOperator::Minus
+ * (compute_value.rs:210-216: BinaryOperatorNotImplemented); with 1 the oracle evaluates it as arrow-arith
+ * numeric::sub (checked integers, IEEE floats) so the product's opt-in "enable_minus" option has a checker.
+ * Process-wide; tests switch it on around the Minus cases only. */
+void oc_set_extension_minus(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,7 @@ def lib():
         "oc_compute_value": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_int), cp, C.c_int]),
         "oc_filter_record": (C.c_int, [vp, vp, C.POINTER(vp), cp, C.c_int]),
         "oc_project_record": (C.c_int, [C.POINTER(_Item), C.c_int, vp, C.POINTER(vp), cp, C.c_int]),
+        "oc_set_extension_minus": (None, [C.c_int]),
         "oc_filter_table_batched": (C.c_int, [vp, vp, i64, C.POINTER(i64), C.POINTER(C.c_double), cp, C.c_int]),
         "oc_filter_project_table_batched": (C.c_int, [vp, vp, C.POINTER(_Item), C.c_int, i64, C.POINTER(i64),
                                                       C.POINTER(C.c_double), cp, C.c_int]),
@@ -90,6 +91,20 @@ def lib():
         f.restype, f.argtypes = res, args
     _lib = L
     return L
+
+
+class extension_minus:
+    """Context manager: NON-REFERENCE mode in which BinaryOperator::Minus evaluates as arrow-arith numeric::sub (the
+    reference returns BinaryOperatorNotImplemented, compute_value.rs:210-216).  Checker for the product's opt-in
+    `enable_minus` option only."""
+
+    def __enter__(self):
+        lib().oc_set_extension_minus(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().oc_set_extension_minus(0)
+        return False
 
 
 # ------------------------------------------------------------------------------------ expr -> oc_expr

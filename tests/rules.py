@@ -50,6 +50,16 @@ def batch_nulls():
     ], names=["a", "b", "t", "s", "f"])
 
 
+def batch_min():
+    """MIN of every signed width next to a -1 and a 7 of the same type (a literal -1 cannot be written: the reference has
+    no unary minus, compute_value.rs:338-342)."""
+    cols, names = [], []
+    for name, typ, lo in (("m8", pa.int8(), -2**7), ("m16", pa.int16(), -2**15), ("m32", pa.int32(), -2**31), ("m64", pa.int64(), -2**63)):
+        cols += [pa.array([7, lo, 9], typ), pa.array([-1, -1, -1], typ), pa.array([7, 13, 9], typ)]
+        names += [name, name.replace("m", "n"), name.replace("m", "p")]
+    return pa.RecordBatch.from_arrays(cols, names=names)
+
+
 def batch_strings():
     return pa.RecordBatch.from_arrays([
         pa.array(["b", "a", "", "ab", "abc", "bé", "B"], pa.utf8()),
@@ -84,6 +94,25 @@ RULES = [
     ("first_offending_row_decides_the_error", batch_ints, "error", "i / j", 20),
     ("int_div_truncates", batch_ints, "value", "i / 2", (pa.int32(), [0, -3, 1073741823, -1073741824, 0, 4])),
     ("int_rem_sign_of_dividend", batch_ints, "value", "i % 4", (pa.int32(), [1, -3, 3, 0, 0, 1])),
+    # MIN / -1 and MIN % -1 (unpinned-by-reference; arrow-rs is not in the container).  Encoded behaviour = arrow-arith 53
+    # numeric.rs: `Op::Div => try_op!(.., l.div_checked(r))`, `Op::Rem => try_op!(.., l.mod_checked(r))`, and
+    # ArrowNativeTypeOp::{div,mod}_checked for integers = zero check (DivideByZero) then `checked_div` / `checked_rem`,
+    # both None for MIN op -1 => ArrowError::ArithmeticOverflow("Overflow happened on: MIN % -1"); the doc comment of
+    # numeric::rem says "Overflow or division by zero will result in an error".  The alternative reading (the pre-numeric
+    # arithmetic::modulus kernel: zero check + mod_wrapping => MIN % -1 = 0) is what the round-1 review recalled; if a
+    # maintainer shows arrow 53.x does that, flip these four `rem` rows to a "value" row with 0 and change
+    # kernels.hip `Interp::arith` / chq_oracle.c INT_ARITH together.
+    ("i8_min_div_neg1_overflows", batch_min, "error", "m8 / n8", 20),
+    ("i16_min_div_neg1_overflows", batch_min, "error", "m16 / n16", 20),
+    ("i32_min_div_neg1_overflows", batch_min, "error", "m32 / n32", 20),
+    ("i64_min_div_neg1_overflows", batch_min, "error", "m64 / n64", 20),
+    ("i8_min_rem_neg1_overflows", batch_min, "error", "m8 % n8", 20),
+    ("i16_min_rem_neg1_overflows", batch_min, "error", "m16 % n16", 20),
+    ("i32_min_rem_neg1_overflows", batch_min, "error", "m32 % n32", 20),
+    ("i64_min_rem_neg1_overflows", batch_min, "error", "m64 % n64", 20),
+    ("rem_neg1_is_zero_away_from_min", batch_min, "value", "p32 % n32", (pa.int32(), [0, 0, 0])),
+    ("div_neg1_negates_away_from_min", batch_min, "value", "p64 / n64", (pa.int64(), [-7, -13, -9])),
+    ("i8_rem_neg1_is_zero_away_from_min", batch_min, "value", "p8 % n8", (pa.int8(), [0, 0, 0])),
     ("uint8_add_checked", batch_ints, "error", "u8 + u8", 20),
     ("int8_mul_checked", batch_ints, "error", "i8 * i8", 20),
     ("widening_u8_to_i32", batch_ints, "value", "u8 + 1000", (pa.int32(), [1100, 1200, 1255, 1000, 1001, 1002])),
@@ -131,6 +160,43 @@ RULES = [
     ("where_true_keeps_first_row_only", batch_ints, "filter", "true", [0]),
     ("where_false_keeps_nothing", batch_ints, "filter", "false", []),
     ("where_constant_comparison", batch_ints, "filter", "1 < 2", [0]),
+]
+
+def batch_minus():
+    return pa.RecordBatch.from_arrays([
+        pa.array([5, 0, 200], pa.uint8()), pa.array([3, 1, 100], pa.uint8()), pa.array([7, 2, 201], pa.uint8()),
+        pa.array([-128, 127, 5], pa.int8()), pa.array([1, -1, 5], pa.int8()),
+        pa.array([-2**63, 5, 2**63 - 1], pa.int64()), pa.array([1, 7, -1], pa.int64()),
+        pa.array([0, 5, 2**64 - 1], pa.uint64()), pa.array([1, 5, 0], pa.uint64()),
+        pa.array([1.5, 0.25, -4.0], pa.float64()),
+    ], names=["a", "b", "c", "x8", "y8", "x64", "y64", "ux", "uy", "d"])
+
+
+# BinaryOperator::Minus -- NOT reference behaviour (compute_value.rs:210-216 has no Minus arm; "minus_not_implemented"
+# above is the reference's answer).  These rows describe the product's opt-in `enable_minus` option = arrow-arith
+# numeric::sub: checked for integers, IEEE for floats, same coercion / null / scalar rules as Plus.  Checked against the
+# oracle's clearly labelled extension mode (O.extension_minus) on the CPU and against the library on the GPU.
+MINUS_RULES = [
+    ("minus_i32", batch_ints, "value", "j - 1", (pa.int32(), [2, 1, 0, -2, 4, -1])),
+    ("minus_i32_overflow", batch_ints, "error", "i - 1", 20),
+    ("minus_literal_on_the_left", batch_ints, "value", "10 - j", (pa.int32(), [7, 8, 9, 11, 5, 10])),
+    ("minus_float_literal_on_the_left", batch_ints, "value", "2.5 - j", (pa.float32(), [-0.5, 0.5, 1.5, 3.5, -2.5, 2.5])),
+    ("minus_u8_widens_with_literal", batch_ints, "value", "u8 - 1", (pa.int32(), [99, 199, 254, -1, 0, 1])),
+    ("minus_u8_same_type", batch_minus, "value", "c - a", (pa.uint8(), [2, 2, 1])),
+    ("minus_u8_underflow", batch_minus, "error", "a - b", 20),
+    ("minus_i8_overflow", batch_minus, "error", "x8 - y8", 20),
+    ("minus_i8_to_i32_no_overflow", batch_minus, "value", "x8 - 1", (pa.int32(), [-129, 126, 4])),
+    ("minus_i64_overflow_low", batch_minus, "error", "x64 - y64", 20),
+    ("minus_i64", batch_minus, "value", "y64 - 3000000000", (pa.int64(), [-2999999999, -2999999993, -3000000001])),
+    ("minus_u64_underflow", batch_minus, "error", "ux - uy", 20),
+    ("minus_u64", batch_minus, "value", "ux - ux", (pa.uint64(), [0, 0, 0])),
+    ("minus_f64", batch_minus, "value", "d - 0.5", (pa.float64(), [1.0, -0.25, -4.5])),
+    ("minus_f32_ieee", batch_floats, "value", "x - y", (pa.float32(), [-0.0, 0.0, NAN, NAN, -INF, 0.0, NAN])),
+    ("minus_nulls_union", batch_nulls, "value", "a - b", (pa.int32(), [-9, None, None, -36, None, 6])),
+    ("minus_constants_fold_to_scalar", batch_ints, "value", "5 - 3", (pa.int32(), [2])),
+    ("minus_constant_overflow", batch_ints, "error", "0 - 2147483647 - 2", 20),
+    ("minus_in_predicate", batch_ints, "filter", "i > 10 - 1", [2]),
+    ("minus_mixed_with_other_ops", batch_ints, "value", "j * 2 - j / 1", (pa.int32(), [3, 2, 1, -1, 5, 0])),
 ]
 
 PROJECT_RULES = [

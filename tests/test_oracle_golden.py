@@ -42,6 +42,47 @@ def test_oracle_project_errors(rule):
     run_project_error(O, rule)
 
 
+@pytest.mark.parametrize("rule", rules.MINUS_RULES, ids=[r[0] for r in rules.MINUS_RULES])
+def test_oracle_minus_extension(rule):
+    """NOT reference behaviour: the oracle's extension mode that checks the product's opt-in `enable_minus`"""
+    with O.extension_minus():
+        run_rule(O, rule)
+
+
+def test_oracle_minus_is_off_by_default_and_after_the_extension_block():
+    rec = rules.batch_ints()
+    with O.extension_minus():
+        O.compute_value(rec, empty_aliases(rec), parse_expr("j - 1"))
+    with pytest.raises(O.OracleError) as ei:
+        O.compute_value(rec, empty_aliases(rec), parse_expr("j - 1"))
+    assert ei.value.code == 3   # BinaryOperatorNotImplemented, compute_value.rs:210-216
+
+
+def test_oracle_minus_vs_numpy():
+    """sub cross-checked against numpy (wrapping ints checked by hand for range, IEEE floats bit for bit)"""
+    rng = np.random.default_rng(5)
+    n = 5000
+    a = rng.integers(-2**31, 2**31, n).astype(np.int32)
+    b = rng.integers(-2**20, 2**20, n).astype(np.int32)
+    x = (rng.random(n) * 200 - 100).astype(np.float32)
+    y = (rng.random(n) * 200 - 100).astype(np.float32)
+    rec = pa.RecordBatch.from_arrays([pa.array(a), pa.array(b), pa.array(x), pa.array(y)], names=["a", "b", "x", "y"])
+    al = empty_aliases(rec)
+    with O.extension_minus():
+        got = O.compute_value(rec, al, parse_expr("x - y"))[0]
+        assert got.to_numpy().view(np.uint32).tolist() == (x - y).view(np.uint32).tolist()
+        wide = a.astype(np.int64) - b.astype(np.int64)
+        fits = (wide >= -2**31).all() and (wide < 2**31).all()
+        if fits:
+            assert O.compute_value(rec, al, parse_expr("a - b"))[0].to_pylist() == wide.tolist()
+        else:
+            with pytest.raises(O.OracleError) as ei:
+                O.compute_value(rec, al, parse_expr("a - b"))
+            assert ei.value.code == 20
+        small = rec.slice(0, 0)
+        assert len(O.compute_value(small, al, parse_expr("a - b"))[0]) == 0
+
+
 # ---- secondary cross-check: Arrow C++ (pyarrow) / numpy, only where semantics coincide (SURVEY.md 8c) --------
 def _rand_batch(n, seed):
     rng = np.random.default_rng(seed)

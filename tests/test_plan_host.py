@@ -22,9 +22,12 @@ TYPE_NAMES = {pa.bool_(): "Boolean", pa.int8(): "Int8", pa.int16(): "Int16", pa.
 DATA_DEPENDENT = {20, 21}   # overflow / divide by zero: only the data can tell (unless the operands are literals)
 
 
+MINUS = {"on": False}   # tests of the opt-in `enable_minus` option flip this (and the oracle's extension mode) together
+
+
 def describe(rec, al, sql):
     try:
-        return 0, chq.plan_describe(rec.schema, al, parse_expr(sql), rec.num_rows)
+        return 0, chq.plan_describe(rec.schema, al, parse_expr(sql), rec.num_rows, enable_minus=MINUS["on"])
     except chq.ChqError as e:
         return e.code, str(e)
 
@@ -56,7 +59,7 @@ def check(rec, al, sql):
         # the host half cannot see the data: it reports OK, or the static error the engine holds back until the sub-trees
         # evaluated before it have run on the device (TypedExpr::pending_code)
         return "data-dependent"
-    if ocode == 30 or code == 30:
+    if ocode == 30 and code == 30:
         return "unsupported"
     assert code == ocode, f"{sql}: oracle status {ocode}, host planner status {code} ({text})"
     if code:
@@ -79,6 +82,40 @@ def test_rules_table_through_the_host_planner(rule):
     _, factory, _, sql, _ = rule
     rec = factory()
     check(rec, empty_aliases(rec), sql)
+
+
+@pytest.fixture
+def minus_mode():
+    MINUS["on"] = True
+    with O.extension_minus():
+        yield
+    MINUS["on"] = False
+
+
+@pytest.mark.parametrize("rule", rules.MINUS_RULES, ids=lambda r: r[0])
+def test_minus_rules_through_the_host_planner(rule, minus_mode):
+    """`enable_minus` (not reference behaviour): typing, folding and static errors of Minus vs the oracle's extension mode"""
+    _, factory, _, sql, _ = rule
+    rec = factory()
+    check(rec, empty_aliases(rec), sql)
+
+
+def test_minus_every_pair_of_types_and_literals(minus_mode):
+    rec = typed_batch(4)
+    al = empty_aliases(rec)
+    operands = list(COLS) + ["3", "2.5", "3000000000", "'x1'", "true"]
+    counts = {}
+    for a in operands:
+        for b in operands:
+            r = check(rec, al, f"{a} - {b}")
+            counts[r] = counts.get(r, 0) + 1
+    assert counts["ok"] > 50 and counts["error"] > 50, counts
+
+
+def test_minus_is_rejected_without_the_option():
+    rec = typed_batch(4)
+    code, _ = describe(rec, empty_aliases(rec), "i32 - 1")
+    assert code == 3   # BinaryOperatorNotImplemented (compute_value.rs:210-216)
 
 
 def test_reference_vectors_type_the_same_way():
