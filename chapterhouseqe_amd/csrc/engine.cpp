@@ -141,20 +141,7 @@ static void parse_format(const char* f, DType* t, int* width) {
       default: break;
     }
   }
-  std::string s(f ? f : "");
-  if (s == "b") { *t = T_BOOL; return; }
-  if (s == "c") { *t = T_I8; *width = 1; return; }
-  if (s == "C") { *t = T_U8; *width = 1; return; }
-  if (s == "s") { *t = T_I16; *width = 2; return; }
-  if (s == "S") { *t = T_U16; *width = 2; return; }
-  if (s == "i") { *t = T_I32; *width = 4; return; }
-  if (s == "I") { *t = T_U32; *width = 4; return; }
-  if (s == "l") { *t = T_I64; *width = 8; return; }
-  if (s == "L") { *t = T_U64; *width = 8; return; }
-  if (s == "e") { *t = T_F16; *width = 2; return; }
-  if (s == "f") { *t = T_F32; *width = 4; return; }
-  if (s == "g") { *t = T_F64; *width = 8; return; }
-  if (s == "u") { *t = T_UTF8; return; }
+  const std::string s(f ? f : "");   // multi-character formats: opaque fixed-width types that are only copied
   *t = T_FIXED_OPAQUE;
   if (s == "tdD" || s == "tts" || s == "ttm") { *width = 4; return; }
   if (s == "tdm" || s == "ttu" || s == "ttn" || s.rfind("ts", 0) == 0 || s.rfind("tD", 0) == 0) { *width = 8; return; }
@@ -186,12 +173,12 @@ Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema) {
   for (int64_t i = 0; i < a.n_children; ++i) {
     const ArrowArray* ca = a.children[i];
     const ArrowSchema* cs = schema->children[i];
+    if (!ca || !cs) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "missing child array or schema"};
     Column c;
     c.name = cs->name ? cs->name : "";
     c.format = cs->format ? cs->format : "";
     parse_format(cs->format, &c.type, &c.width);
     c.nullable = (cs->flags & ARROW_FLAG_NULLABLE) != 0;
-    if (!ca || !cs) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "missing child array or schema"};
     if (ca->length < b.nrows) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "column shorter than the record batch"};
     if (ca->offset < 0 || b.nrows < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "negative length or offset"};
     // a kernel must never be handed a null data pointer: refuse malformed arrays here, on the host
@@ -892,9 +879,9 @@ bool filter_record_small_host(Context& ctx, const Batch& rec, const chq_table_al
     if (ctx.pinned_io) (void)hipHostFree(ctx.pinned_io);
     ctx.pinned_io = nullptr; ctx.pinned_io_bytes = 0;
     const size_t cap = std::max<size_t>(2 * block + 64, (size_t)1 << 20);
+    ctx.dev_io = make_device_buffer(cap, ctx.device);   // may throw: the capacity is recorded only once both halves exist
     check_hip(hipHostMalloc(&ctx.pinned_io, cap, hipHostMallocDefault), "hipHostMalloc (small host path)");
     ctx.pinned_io_bytes = cap;
-    ctx.dev_io = make_device_buffer(cap, ctx.device);
   }
   uint8_t* h_in = (uint8_t*)ctx.pinned_io; uint8_t* h_out = h_in + block;
   uint8_t* d_in = (uint8_t*)ctx.dev_io->ptr; uint8_t* d_out = d_in + block;
@@ -1062,6 +1049,11 @@ Batch concat_host_batches(const std::vector<Batch>& recs, size_t b0, size_t b1) 
         if (c.values && c.length) { const int32_t* offs = (const int32_t*)c.values + c.offset; nbytes = (int64_t)offs[c.length] - offs[0]; }
         row_at[k + 1] = row_at[k] + c.length; byte_at[k + 1] = byte_at[k] + nbytes;
       }
+      // Arrow Utf8 offsets are int32: a joined column of 2 GiB or more cannot be represented (arrow's concat reports
+      // an offset overflow; wrapping silently would hand out negative offsets)
+      if (byte_at[n] > (int64_t)INT32_MAX)
+        throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "offset overflow: Utf8 column '" + c0.name + "' of the joined batches holds " +
+                                                           std::to_string(byte_at[n]) + " bytes, more than int32 offsets can address"};
       auto ob = make_host_buffer((size_t)(total + 1) * 4 + 16);
       auto db = make_host_buffer((size_t)byte_at[n] + 16);
       int32_t* oo = (int32_t*)ob->ptr;

@@ -194,6 +194,11 @@ def send_device_record(rec, record_id: int, dst: int, table_aliases=None) -> Non
     dist.send(blob, dst)
     for t in tensors:
         dist.send(t, dst)
+    # With RCCL the sends are only enqueued (on torch's current stream).  The tensors are zero-copy views of the batch's
+    # HBM buffers, not caching-allocator memory: once the caller acks the record the buffers may go back to the library's
+    # pool and be reused by a chq call on another stream.  Drain the sends before returning (gloo sends are synchronous).
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
 
 
 def recv_device_record(src: int, ctx):
@@ -213,6 +218,9 @@ def recv_device_record(src: int, ctx):
                 t = torch.empty(c["sizes"][key] + 16, dtype=torch.uint8, device=device)[: c["sizes"][key]]
                 dist.recv(t, src)
                 tensors.append(t)
+    # the batch is handed to a chq context that launches on its OWN stream with no sync_event: every byte must have
+    # landed before it is wrapped
+    torch.cuda.current_stream(device).synchronize()
     return header["record_id"], tensors_to_device_record(header, tensors, ctx), header.get("table_aliases")
 
 

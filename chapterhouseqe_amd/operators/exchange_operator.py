@@ -132,6 +132,10 @@ class ExchangeOperator:
         self._lock = threading.Lock()
         self._pool = RecordPool(outbound_producer_ids, max_heartbeat_interval_s)
         self.received_all_data_from_producers = False
+        # the reference's RecordPoolMaintainer wakes every 100 ms (exchange_operator.rs:798-818); here the same sweep runs
+        # inside get_next_record, at most once per interval (not on every pull: the sweep scans all reservations)
+        self.maintain_interval_s = 0.1
+        self._last_maintain = 0.0
 
     def send_record(self, record_id: int, record: Any, table_aliases: List[List[str]]) -> bool:
         with self._lock:
@@ -139,7 +143,10 @@ class ExchangeOperator:
 
     def get_next_record(self, operator_id: str, operator_instance_id: int):
         with self._lock:
-            self._pool.maintain()
+            now = time.monotonic()
+            if now - self._last_maintain >= self.maintain_interval_s:
+                self._last_maintain = now
+                self._pool.maintain()
             got = self._pool.get_next_record(operator_id, operator_instance_id)
             if got is not None:
                 return got

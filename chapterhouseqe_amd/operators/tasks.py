@@ -154,23 +154,25 @@ class FilterTask:
     def async_main(self) -> None:
         """filter_task.rs:65-142: pull -> filter -> push (same record id) -> ack"""
         rec_handler = RecordHandler.initiate(self.operator_instance_config, self.inbound_exchanges, self.outbound_exchange)
-        while True:
-            exchange_rec = rec_handler.next_record()
-            if exchange_rec is None:
-                break
-            group = [exchange_rec]
-            while len(group) < self.group_size:
-                more = rec_handler.try_next_record()
-                if more is None:
+        try:   # an error ends the task (filter_task.rs `?`): its heartbeats must stop with it, so the exchange requeues
+            while True:
+                exchange_rec = rec_handler.next_record()
+                if exchange_rec is None:
                     break
-                group.append(more)
-            for exchange_rec, filtered_rec in zip(group, self._filter_group(group)):
-                rec_handler.send_record_to_outbound_exchange(exchange_rec.record_id, filtered_rec, exchange_rec.table_aliases)
-                rec_handler.complete_record(exchange_rec)
-                self.records_processed += 1
-                self.rows_in += exchange_rec.record.num_rows
-                self.rows_out += filtered_rec.num_rows
-        rec_handler.close()
+                group = [exchange_rec]
+                while len(group) < self.group_size:
+                    more = rec_handler.try_next_record()
+                    if more is None:
+                        break
+                    group.append(more)
+                for exchange_rec, filtered_rec in zip(group, self._filter_group(group)):
+                    rec_handler.send_record_to_outbound_exchange(exchange_rec.record_id, filtered_rec, exchange_rec.table_aliases)
+                    rec_handler.complete_record(exchange_rec)
+                    self.records_processed += 1
+                    self.rows_in += exchange_rec.record.num_rows
+                    self.rows_out += filtered_rec.num_rows
+        finally:
+            rec_handler.close()
 
 
 def _schema_of(rec):
@@ -242,19 +244,21 @@ class MaterializeFilesTask:
         query_uuid = uuid.UUID(int=self.operator_instance_config.query_id)
         out_dir = os.path.join(self.storage_root, "query_results", str(query_uuid))
         os.makedirs(out_dir, exist_ok=True)
-        while True:
-            exchange_rec = rec_handler.next_record()
-            if exchange_rec is None:
-                break
-            proj_rec = self._project_record(exchange_rec.record, exchange_rec.table_aliases)
-            if hasattr(proj_rec, "to_host"):
-                proj_rec = proj_rec.to_host()
-            path = os.path.join(out_dir, f"rec_{exchange_rec.record_id}.parquet")
-            import pyarrow as pa
-            pq.write_table(pa.Table.from_batches([proj_rec]), path)
-            self.files_written.append(path)
-            rec_handler.complete_record(exchange_rec)
-        rec_handler.close()
+        import pyarrow as pa
+        try:
+            while True:
+                exchange_rec = rec_handler.next_record()
+                if exchange_rec is None:
+                    break
+                proj_rec = self._project_record(exchange_rec.record, exchange_rec.table_aliases)
+                if hasattr(proj_rec, "to_host"):
+                    proj_rec = proj_rec.to_host()
+                path = os.path.join(out_dir, f"rec_{exchange_rec.record_id}.parquet")
+                pq.write_table(pa.Table.from_batches([proj_rec]), path)
+                self.files_written.append(path)
+                rec_handler.complete_record(exchange_rec)
+        finally:
+            rec_handler.close()
 
 
 class MaterializeFilesTaskBuilder(TaskBuilder):

@@ -1,4 +1,4 @@
-"""Seeded regeneration of the reference's sample data sets and its sample queries.
+"""Seeded regeneration of the reference's sample data sets.
 
 The reference writes its samples with an UNSEEDED `rand::thread_rng` (src/bin/create_sample_data.rs:172-189), so
 there is no canonical file to compare against; this module reproduces the schema and the distributions
@@ -11,17 +11,6 @@ from typing import List
 
 import numpy as np
 import pyarrow as pa
-
-# reference: sample_queries/simple.sql (text reproduced: it is the workload definition of BASELINE config 1)
-SIMPLE_SQL = """
-select * from read_files('sample_data/simple/*.parquet') where id < 25;
-select * from read_files('sample_data/simple_wide_string/*.parquet') where id > 25;
-select id, value2 from read_files('sample_data/simple/*.parquet') where id < 75;
-select id, value1, id + 10.0 as id_plus_10, (value2 + 10) / 100 as value2, 1.0 / id as value3,
-       1.0 / (id * id) as value4, id * id as value5
-  from read_files('sample_data/simple/*.parquet') where id > 25 + 0.0;
-select * from read_files('sample_data/simple/*.parquet') where id % 2 = 0;
-"""
 
 SCHEMA = pa.schema([pa.field("id", pa.int32(), False), pa.field("value1", pa.utf8(), False),
                     pa.field("value2", pa.float32(), False)])

@@ -108,3 +108,8 @@ def explain_diff(a: pa.RecordBatch, b: pa.RecordBatch) -> str:
             bad = [k for k in range(len(la)) if la[k] != lb[k] and not (la[k] != la[k] and lb[k] != lb[k])][:5]
             out.append(f"column {i} ({fa.name}) differs at rows {bad}: {[la[k] for k in bad]} vs {[lb[k] for k in bad]} nulls {a.column(i).null_count} vs {b.column(i).null_count}")
     return "\n".join(out)
+
+
+def load_simple_sql() -> str:
+    """the five statements of the reference's sample_queries/simple.sql (BASELINE config 1), kept as a data fixture"""
+    return ";\n".join(load_golden("simple_sql.json")["statements"]) + ";"

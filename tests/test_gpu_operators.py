@@ -130,10 +130,10 @@ def _p2p_worker(rank, port, q):
 
 
 def test_filtered_batch_moves_gpu_to_gpu_over_rccl():
-    """two ranks, two GPUs, backend nccl (= RCCL): skipped on a one-GPU box"""
+    """two ranks, two GPUs, backend nccl (= RCCL): runs wherever at least two GPUs are visible"""
     import torch
-    if torch.cuda.device_count() < 2 or os.environ.get("CHQ_TEST_MULTI_GPU") != "1":
-        pytest.skip("needs two GPUs and CHQ_TEST_MULTI_GPU=1 (never exercised on the one-GPU development boxes)")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the development boxes have one)")
     import torch.multiprocessing as mp
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()

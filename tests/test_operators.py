@@ -124,6 +124,68 @@ def test_filter_exchange_materialize_pipeline(tmp_path, instances):
         assert got.to_pydict() == exp.to_pydict()
 
 
+def test_slow_records_are_processed_exactly_once_with_two_instances(tmp_path):
+    """A record held longer than the exchange's max heartbeat interval must not be handed to a second instance: the
+    RecordHandler renews the heartbeat of every tracked record every 100 ms (record_handler.rs:167-184,
+    heartbeat_handler.rs:78-82) and the pool only requeues reservations whose heartbeat went stale
+    (exchange_operator.rs:746-776)."""
+    import time
+    batches = simple_batches(600, 8, 100)          # 6 records
+    seen, lock = [], threading.Lock()
+
+    def slow_filter(rec, aliases, expr):
+        with lock:
+            seen.append(rec.column(0)[0].as_py())
+        time.sleep(0.45)                           # > max_heartbeat_interval_s (0.3 s below), several times over per group
+        return O.filter_record(rec, aliases, expr)
+
+    sel = parse_select("select id from read_files('x') where id % 2 = 0")
+    ex_in = ExchangeOperator("operator_p0_exchange", ["operator_p1_producer"], max_heartbeat_interval_s=0.3)
+    ex_mid = ExchangeOperator("operator_p1_exchange", ["operator_p2_producer"])
+    for rid, b in enumerate(batches):
+        ex_in.send_record(rid, b, [[] for _ in range(b.num_columns)])
+    ex_in.producers_completed()
+    ftask = FilterOperatorTask(sel.selection)
+    builder = FilterTaskBuilder(slow_filter, group_size=2)      # a drained group holds its second record for 0.9 s
+    runs = [builder.build(OperatorInstanceConfig(i + 1, "operator_p1_producer", 7, ftask), [ex_in], ex_mid) for i in range(2)]
+    errs = [None, None]
+    threads = [threading.Thread(target=lambda k=k: errs.__setitem__(k, runs[k]())) for k in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert errs == [None, None], errs                             # no "reserved record instance missing"
+    assert sorted(seen) == sorted(b.column(0)[0].as_py() for b in batches)    # every record filtered exactly once
+    assert sum(r.task.records_processed for r in runs) == len(batches)
+    assert ex_in.num_records() == 0 and ex_mid.num_records() == len(batches)
+
+
+def test_a_dead_instance_stops_heartbeating_and_its_record_is_requeued():
+    """the other half of the protocol: when the instance holding a record goes away (task error -> RecordHandler.close),
+    the heartbeat stops, the reservation goes stale and another instance gets the record (failure_count bumped)"""
+    import time
+    from chapterhouseqe_amd.operators.record_handler import RecordHandler
+    ex = ExchangeOperator("operator_p0_exchange", ["op"], max_heartbeat_interval_s=0.25)
+    ex.send_record(5, "payload", [[]])
+    ex.producers_completed()
+    h1 = RecordHandler("op", 1, [ex], None)
+    h2 = RecordHandler("op", 2, [ex], None)
+    got = h1.next_record()
+    assert got.record_id == 5
+    time.sleep(0.6)                                               # alive and beating: still reserved
+    assert h2.try_next_record() is None
+    h1.close()                                                    # instance 1 dies without acking
+    time.sleep(0.6)
+    q = ex._pool.queues[0]
+    with ex._lock:
+        ex._pool.maintain()                                       # what the 100 ms maintainer does (:798-818)
+    assert list(q.records_to_process) == [5] and q.record_processing_metrics[5] == 1   # requeued, failure_count bumped (:768-773)
+    again = h2.next_record(max_wait_s=2.0)
+    assert again is not None and again.record_id == 5
+    assert q.record_processing_metrics[5] == 0                    # the reference resets the metrics on every reservation (:655-657)
+    h2.complete_record(again)
+    h2.close()
+    assert ex.num_records() == 0
+
+
 def test_group_size_drains_the_queue_but_keeps_the_protocol(tmp_path):
     """group_size > 1 (GPU extension): several queued records per pull, still one output and one ack per record id"""
     batches = simple_batches(1000, 8, 33)

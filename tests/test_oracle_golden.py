@@ -136,7 +136,9 @@ def test_simple_sql_sample_queries_on_regenerated_dataset():
     reference's operator sequence (filter on the full-width batch, then projection) on a regenerated `simple`
     data set: id = 0..99, value1 = 8 lowercase chars, value2 ~ U[0,100) (create_sample_data.rs:157-204), cut
     into 33-row files/batches (create_sample_data.rs:139)."""
-    from chapterhouseqe_amd.sample_data import SIMPLE_SQL, simple_batches
+    from chapterhouseqe_amd.sample_data import simple_batches
+    from .helpers import load_simple_sql
+    SIMPLE_SQL = load_simple_sql()
     batches = simple_batches(size=100, string_size=8, rows_per_file=33, seed=0xC0FFEE)
     assert [b.num_rows for b in batches] == [33, 33, 33, 1]
     from chapterhouseqe_amd.sqlparse import parse_statements
