@@ -12,6 +12,8 @@ read-back of the output row count (the Arrow length the caller needs).  Inputs a
 N > 1: one operator instance per GPU (one process per GPU), each filtering its own `--rows`-row shard of an
 N x rows table -- batches are independent in the reference (filter_task.rs:86-125), so there is no data-path
 collective; ranks only all-reduce the elapsed time (MAX) and row counts (SUM) after the timed region ("weak").
+Started without WORLD_SIZE in the environment, `--gpus N` launches the N ranks itself (child processes through
+torch.distributed.run on 127.0.0.1, before this process has imported torch or touched a GPU) and exits with their code.
 
 Prints ONE JSON line on rank 0 with the driver's fields plus `roofline` (dominant kernel vs HBM peak) and
 `cpu_baseline` (the C oracle = CPU restatement of the reference path, timed on this box's host cores).
@@ -40,11 +42,80 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="context option key=value (experiments)")
     ap.add_argument("--validate-rows", type=int, default=4_000_000, help="prefix checked bit-exact against the oracle")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra config-3 / reference-schema lines (N = 1 only)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU: every rank joins a gloo group, runs the barrier / MAX / SUM protocol of the timed region on "
+                         "dummy numbers and rank 0 prints the JSON line (tests the N-rank launch path on CPU)")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="with --launcher-selftest: this rank exits non-zero")
     return ap.parse_args()
+
+
+def self_launch(n_ranks, argv):
+    """`--gpus N` without a launcher: start the N ranks as children (one process per GPU, rendezvous on 127.0.0.1) and
+    return their exit code.  Runs before this process imports torch or touches a GPU -- never re-exec a process that has."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(args):
+    """The multi-rank protocol of main() on CPU (gloo): barrier, timed region, barrier, MAX over ranks, SUM of counts,
+    ONE JSON line from rank 0, non-zero exit when a rank fails."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    if rank == args.selftest_fail_rank:
+        raise SystemExit(3)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rows = 1000 * (rank + 1)
+    per_rank = [rows / elapsed]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([rows], dtype=torch.int64)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rows = int(rr.item())
+        gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(per_rank, dtype=torch.float64))
+        per_rank = [float(g.item()) for g in gathered]
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "value": rows / elapsed, "per_gpu_rows_per_s": per_rank,
+                          "rows_total": rows}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def kernel_source_hash():
+    """sha256 over the device sources: ties a committed PMC summary to the binary it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "device_program.h"):
+        h.update(open(os.path.join(ROOT, "chapterhouseqe_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launcher_selftest:
+        return launcher_selftest(args)
     import torch
     import torch.distributed as dist
 
@@ -132,7 +203,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     rows_out = stats["rows_out"]
+    per_gpu = [n * args.steps / elapsed]     # every rank's own rate; `value` uses the MAX elapsed time over the ranks
     if world > 1:
+        gathered = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(per_gpu, dtype=torch.float64, device=dev))
+        per_gpu = [float(g.item()) for g in gathered]
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -154,12 +229,16 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3 passes of
         # this same command; the counters cannot be read from inside the process, so the committed summary is quoted)
+        # a summary is only quoted for the kernel sources it was measured on (it carries their hash)
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1", "bench_pmc_hbm_v3.json")
+        pmc = os.path.join(ROOT, "profiles", "r2", "bench_pmc_hbm.json")
         if os.path.exists(pmc) and args.predicate == PREDICATE and n == 1_000_000_000:
             j = json.load(open(pmc))
-            traffic = j["fetch_bytes_corrected"] + j["write_bytes"]
-            traffic_src = "profiles/r1/bench_pmc_hbm_v3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command)"
+            if j.get("kernel_source_sha256") == kernel_source_hash():
+                traffic = j["fetch_bytes_corrected"] + j["write_bytes"]
+                traffic_src = "profiles/r2/bench_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, same kernel sources)"
+            else:
+                traffic_src = "profiles/r2/bench_pmc_hbm.json is stale: the kernel sources changed since that PMC pass"
         # a plain device copy measured in this same process, so the fraction is not hostage to the datasheet peak
         # (SURVEY.md section 8 d): one column copied into a scratch tensor, read + write bytes / time
         copy_gbps = None
@@ -183,7 +262,8 @@ def main():
             "config": {"workload": f"config 2: SELECT * WHERE {args.predicate} over one {n}-row record batch per GPU, "
                                    "3 x Float32 U[0,100), non-null, inputs and outputs in HBM",
                        "rows_per_gpu": n, "selectivity": rows_out / n, "parallelism": f"1 operator instance per GPU x {world}",
-                       "rows_out_total": rows_out_total, "validated_vs_oracle_rows": args.validate_rows if validated else 0},
+                       "rows_out_total": rows_out_total, "validated_vs_oracle_rows": args.validate_rows if validated else 0,
+                       "per_gpu_rows_per_s": per_gpu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src,

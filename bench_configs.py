@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--where", default=None, help="replace the predicate of the selected case(s) (instruction-cost experiments)")
+    ap.add_argument("--no-select", action="store_true", help="skip the projection / one-pass parts of the selected case(s)")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,6 +89,10 @@ def main():
         if args.only and args.only not in name:
             return
         n = max(1024, int(n * args.scale))
+        if args.where:
+            where = args.where
+        if args.no_select:
+            select = None
         keep, cols = gen(n, spec, seed)
         rec = chq.DeviceRecordBatch.from_device_pointers(cols, n, ctx=ctx, keepalive=keep)
         al = [[] for _ in cols]

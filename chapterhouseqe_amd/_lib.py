@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libchq.so")
+# CHQ_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants); never a fallback
+LIB_PATH = os.environ.get("CHQ_LIB_PATH") or os.path.join(_HERE, "lib", "libchq.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ARROW_DEVICE_CPU = 1
@@ -71,6 +72,7 @@ EXPORTED_SYMBOLS = [
     "chq_expr_boolean", "chq_expr_single_quoted_string", "chq_expr_unsupported_value", "chq_expr_binary_op",
     "chq_expr_nested", "chq_expr_unsupported", "chq_expr_free", "chq_filter_record", "chq_filter_records", "chq_filter_records_coalesced", "chq_plan_describe", "chq_project_record",
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
+    "chq_record_copy_to_peer",
 ]
 
 
@@ -139,9 +141,15 @@ def lib():
         "chq_filter_project_record": (ci, [vp, vp, C.POINTER(SelectItem), ci, PDA, PS, PTA, ci, PDA, PS]),
         "chq_record_to_device": (ci, [vp, PDA, PS, PDA, PS]), "chq_record_to_host": (ci, [vp, PDA, PS, PDA, PS]),
         "chq_wrap_columns": (ci, [vp, C.POINTER(ColumnDesc), ci, i64, ci, PDA, PS]),
+        "chq_record_copy_to_peer": (ci, [vp, vp, PDA, PS, PDA, PS]),
     }
     for name, (res, args) in sig.items():
-        f = getattr(L, name)
+        try:
+            f = getattr(L, name)
+        except AttributeError:
+            if os.environ.get("CHQ_LIB_PATH"):   # an older build under A/B timing: entry points added since are simply absent
+                continue
+            raise
         f.restype, f.argtypes = res, args
     _lib = L
     return L

@@ -109,7 +109,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     if (k == "tile_kind") { if (value < -1 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "tile_kind must be -1..2"}; ctx->c.opt_tile_kind = value; }
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
-    else if (k == "stash") ctx->c.opt_stash = value != 0;
+    else if (k == "stash") { if (value < -1 || value > MAX_STASH) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "stash must be -1..2"}; ctx->c.opt_stash = value; }
     else if (k == "small_host") ctx->c.opt_small_host = value != 0;
     else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
@@ -339,6 +339,19 @@ chq_status chq_record_to_device(chq_ctx* ctx, const ArrowDeviceArray* rec, const
     Batch dev = to_device(ctx->c, in);
     check_hip(hipStreamSynchronize(ctx->c.stream), "hipStreamSynchronize");
     export_batch(std::move(dev), ARROW_DEVICE_ROCM, out, out_schema);
+  });
+}
+
+chq_status chq_record_copy_to_peer(chq_ctx* src_ctx, chq_ctx* dst_ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema,
+                                   ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (!src_ctx || !dst_ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(dst_ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema");
+    Batch in = import_batch(rec, schema);   // waits on rec->sync_event when the producer left one
+    hipEvent_t ev = nullptr;
+    Batch moved = copy_to_peer(src_ctx->c, dst_ctx->c, in, &ev);
+    export_batch(std::move(moved), ARROW_DEVICE_ROCM, out, out_schema, ev);
   });
 }
 

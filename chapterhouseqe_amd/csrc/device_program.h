@@ -82,6 +82,10 @@ constexpr int MAX_PROJ = 16;
 constexpr int MAX_CONST_STR = 4;
 constexpr int MAX_BOOL_TEMPS = 4;
 constexpr int MAX_NUM_TEMPS = 2;
+// LDS stash slots of the filter kernel's instantiations (tile kinds 0..2; device_program.h is shared with the host,
+// which must not ask for more columns than the launched instantiation has slots)
+constexpr int STASH_SLOTS_K0 = 1, STASH_SLOTS_K1 = 2, STASH_SLOTS_K2 = 1;
+constexpr int MAX_STASH = 2;
 
 // error word: the device keeps the bitwise complement of
 //   [63:56] position of the node in the reference's evaluation order, [55:8] row index, [7:0] code
@@ -95,7 +99,29 @@ enum DevErr : uint32_t { DE_OVERFLOW = 1, DE_DIV_ZERO = 2 };
 enum FastKind : int32_t {
   FAST_NONE = 0,
   FAST_CMP_CONST = 1,   // refs[0] (Int32 / UInt32 / Float32, no nulls) <cmp prog[1].op> literal prog[1].imm, e.g. value2 > 10.0
+  FAST_UOPS = 2,        // every instruction is pre-decoded into ProgramBlock::fast_op / fast_opd (below)
 };
+
+// Pre-decoded form of a program over non-null Int32 / UInt32 / Float32 columns (the host fills it when every instruction
+// qualifies).  The generic interpreter classifies types, operand kinds and operators with chains of scalar compares --
+// measured: about 50 branches and 150 scalar instructions per interpreted instruction and wave, more than the vector
+// work of a 16-slot tile -- whereas here ONE jump table selects the operand fetch and one the straight-line loop body.
+enum FastOperand : uint8_t { FO_NONE = 0, FO_COL, FO_COL_I2F, FO_COL_U2F, FO_CONST, FO_BTEMP };
+enum FastOp : uint8_t {
+  FU_LD = 0,                                            // acc = operand (numeric) / boolean temporary
+  FU_ADD_F, FU_SUB_F, FU_RSUB_F, FU_MUL_F, FU_DIV_F, FU_RDIV_F,        // Float32; R*: operand (op) acc
+  FU_ADD_I, FU_SUB_I, FU_RSUB_I, FU_MUL_I,              // Int32, checked
+  FU_ADD_U, FU_SUB_U, FU_RSUB_U, FU_MUL_U,              // UInt32, checked
+  FU_DIVP2_I, FU_REMP2_I, FU_DIVP2_U, FU_REMP2_U,       // by a literal power of two (imm)
+  FU_EQ, FU_LT_I, FU_GT_I, FU_LT_U, FU_GT_U,            // acc (cmp) operand; FU_EQ is bitwise (all three types)
+  FU_LT_F, FU_GT_F,                                     // Float32 totalOrder, both sides keyed
+  FU_LT_FKC, FU_GT_FKC,                                 // Float32 totalOrder against a literal with the sign bit set
+  FU_AND, FU_OR, FU_SPILL,                              // boolean temporaries
+  FU_CVT_I2F, FU_CVT_U2F,                               // acc conversions (OP_CAST)
+  FU_STORE,                                             // projection output
+  FU_NOPS
+};
+constexpr uint8_t FU_NEGATE = 0x80;                     // compares: the result is complemented
 
 struct ProgramBlock {
   int32_t n_instr;
@@ -105,6 +131,8 @@ struct ProgramBlock {
   Instr prog[MAX_INSTR];
   ColRef refs[MAX_REFS];
   ConstStr strs[MAX_CONST_STR];
+  uint8_t fast_op[MAX_INSTR];    // FAST_UOPS: FastOp (| FU_NEGATE) per instruction
+  uint8_t fast_opd[MAX_INSTR];   // FAST_UOPS: FastOperand per instruction
 };
 
 struct FilterParams {
@@ -118,9 +146,10 @@ struct FilterParams {
   u64* sel_mask;     // optional: selection bitmap (one u64 per 64 rows), for follow-up kernels
   u64* grp_base;     // optional: output row index of each 64-row group's first selected row
   int16_t n_out;
-  int16_t stash_ref;      // program column-ref whose raw tile values stay in LDS between P and C (-1: none); when set,
-                          // that column is outs[n_out - 1] and is copied from LDS instead of being fetched again
+  int16_t n_stash;        // program column-refs stash_refs[0..n_stash) keep their raw tile values in LDS between P and C;
+  int8_t stash_refs[4];   // (MAX_STASH used) those columns are outs[n_out - n_stash ..] and are copied from LDS instead of fetched again
   int32_t pad0;
+  int32_t pad1;
   // Batch-group launch (chq_filter_records): many batches of one schema, one launch, one dense compaction.  Tiles never
   // straddle batches; row `tile` of this table (group_stride words) = { first row of the tile inside its batch, rows of
   // that batch, value pointers of the n_refs program inputs, input pointers of the n_out copied columns }.

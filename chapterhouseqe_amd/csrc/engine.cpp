@@ -41,9 +41,15 @@ void* DevicePool::alloc(size_t bytes, int device, size_t* cap_out) {
     auto it = free_.find(pool_key(cap, device));
     if (it != free_.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); return p; }
   }
+  // allocate on the device the block is keyed by, whatever the calling thread's current device is (peer copies
+  // allocate on the destination GPU from a call that started on the source context)
+  int current = device;
+  (void)hipGetDevice(&current);
+  if (current != device) check_hip(hipSetDevice(device), "hipSetDevice");
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, cap);
   if (e == hipErrorOutOfMemory) { trim(); e = hipMalloc(&p, cap); }
+  if (current != device) (void)hipSetDevice(current);
   check_hip(e, "hipMalloc");
   return p;
 }
@@ -211,6 +217,7 @@ struct ArrayHolder {
   std::vector<ArrowArray*> child_ptrs;
   std::vector<ArrowArray> children;
   std::vector<BufferPtr> owned;
+  hipEvent_t event = nullptr;   // ArrowDeviceArray::sync_event points here when set; destroyed with the array
 };
 struct SchemaHolder {
   std::string format, name;
@@ -220,7 +227,11 @@ struct SchemaHolder {
 void release_array(ArrowArray* a) {
   if (!a || !a->release) return;
   auto* h = (ArrayHolder*)a->private_data;
-  if (h) { for (auto& c : h->children) if (c.release) c.release(&c); delete h; }
+  if (h) {
+    for (auto& c : h->children) if (c.release) c.release(&c);
+    if (h->event) { (void)hipEventSynchronize(h->event); (void)hipEventDestroy(h->event); }   // buffers go back to the pool only once the copies behind the event are done
+    delete h;
+  }
   a->release = nullptr; a->private_data = nullptr;
 }
 void release_schema(ArrowSchema* s) {
@@ -251,8 +262,9 @@ void fill_column_schema(const Column& c, ArrowSchema* out) {
 }
 }  // namespace
 
-void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema* out_schema) {
+void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema* out_schema, hipEvent_t sync_event) {
   auto* ah = new ArrayHolder();
+  ah->event = sync_event;
   auto* sh = new SchemaHolder();
   const size_t n = b.cols.size();
   ah->children.resize(n); sh->children.resize(n);
@@ -268,7 +280,7 @@ void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema
   out->array.n_children = (int64_t)n; out->array.children = ah->child_ptrs.data();
   out->array.release = release_array; out->array.private_data = ah;
   out->device_id = device_type == ARROW_DEVICE_ROCM ? b.device_id : -1;
-  out->device_type = device_type; out->sync_event = nullptr;
+  out->device_type = device_type; out->sync_event = ah->event ? (void*)&ah->event : nullptr;
   sh->format = "+s"; sh->name = "";
   memset(out_schema, 0, sizeof(*out_schema));
   out_schema->format = sh->format.c_str(); out_schema->name = sh->name.c_str();
@@ -294,10 +306,15 @@ BitRange bit_range(int64_t offset, int64_t len) {
   int64_t fb = offset >> 3, lb = (offset + len + 7) >> 3;
   return {fb, lb - fb};
 }
-enum class Dir { H2D, D2H, D2D, H2H };
-BufferPtr copy_bytes(Context& ctx, const uint8_t* src, int64_t nbytes, Dir dir, size_t pad = 16) {
+enum class Dir { H2D, D2H, D2D, H2H, P2P };
+// P2P: `ctx` is the DESTINATION context (buffers on its device, copies on its stream), `peer_device` the GPU `src` lives on
+BufferPtr copy_bytes(Context& ctx, const uint8_t* src, int64_t nbytes, Dir dir, size_t pad = 16, int peer_device = -1) {
   BufferPtr out = (dir == Dir::D2H || dir == Dir::H2H) ? make_host_buffer((size_t)nbytes + pad) : make_device_buffer((size_t)nbytes + pad, ctx.device);
   if (dir == Dir::H2H) { if (nbytes > 0) memcpy(out->ptr, src, (size_t)nbytes); return out; }
+  if (dir == Dir::P2P) {
+    if (nbytes > 0) check_hip(hipMemcpyPeerAsync(out->ptr, ctx.device, src, peer_device, (size_t)nbytes, ctx.stream), "hipMemcpyPeerAsync");
+    return out;
+  }
   if (nbytes > 0) {
     hipMemcpyKind k = dir == Dir::H2D ? hipMemcpyHostToDevice : (dir == Dir::D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
     check_hip(hipMemcpyAsync(out->ptr, src, (size_t)nbytes, k, ctx.stream), "hipMemcpyAsync");
@@ -307,7 +324,10 @@ BufferPtr copy_bytes(Context& ctx, const uint8_t* src, int64_t nbytes, Dir dir, 
 
 // Copy one column across (or within) memory spaces; the copy keeps `offset & 7` so that validity,
 // boolean values and value buffers share one Arrow offset.
-Column copy_column(Context& ctx, const Column& c, Dir dir) {
+Column copy_column(Context& ctx, const Column& c, Dir dir, int peer_device = -1) {
+  auto copy_bytes = [peer_device](Context& cx, const uint8_t* src, int64_t nbytes, Dir d, size_t pad = 16) {
+    return chq::copy_bytes(cx, src, nbytes, d, pad, peer_device);
+  };
   Column o;
   o.name = c.name; o.format = c.format; o.type = c.type; o.width = c.width; o.nullable = c.nullable;
   o.length = c.length; o.null_count = c.null_count;
@@ -327,7 +347,7 @@ Column copy_column(Context& ctx, const Column& c, Dir dir) {
     int32_t ends[2] = {0, 0};
     if (c.values) {
       if (dir == Dir::H2D || dir == Dir::H2H) { const int32_t* offs = (const int32_t*)c.values; ends[0] = offs[c.offset]; ends[1] = offs[c.offset + n]; }
-      else {
+      else {   // (unified addressing: the copy finds the source GPU from the pointer, also for a peer's memory)
         check_hip(hipMemcpyAsync(&ends[0], c.values + 4 * c.offset, 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
         check_hip(hipMemcpyAsync(&ends[1], c.values + 4 * (c.offset + n), 4, hipMemcpyDeviceToHost, ctx.stream), "read offsets");
         check_hip(hipStreamSynchronize(ctx.stream), "sync");
@@ -336,7 +356,7 @@ Column copy_column(Context& ctx, const Column& c, Dir dir) {
     auto ob = c.values ? copy_bytes(ctx, c.values + 4 * base, 4 * (n + phase + 1), dir) : copy_bytes(ctx, nullptr, 0, dir);
     if (!c.values) {   // empty array without an offsets buffer: synthesise [0]
       int32_t zero[9] = {0};
-      if (dir == Dir::D2H || dir == Dir::H2H) memcpy(ob->ptr, zero, sizeof zero); else check_hip(hipMemcpy(ob->ptr, zero, 16, hipMemcpyHostToDevice), "memcpy");
+      if (dir == Dir::D2H || dir == Dir::H2H) memcpy(ob->ptr, zero, sizeof zero); else check_hip(hipMemcpyAsync(ob->ptr, zero, 16, hipMemcpyHostToDevice, ctx.stream), "memcpy");
     }
     o.values = (const uint8_t*)ob->ptr; o.owned.push_back(ob);
     const int64_t nb = (int64_t)ends[1] - ends[0];
@@ -373,6 +393,32 @@ Batch to_device(Context& ctx, const Batch& b) {
   return o;
 }
 
+Batch copy_to_peer(Context& src, Context& dst, const Batch& b, hipEvent_t* event_out) {
+  if (!b.on_device) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "chq_record_copy_to_peer moves device-resident batches; stage host batches with chq_record_to_device on the destination context"};
+  check_hip(hipSetDevice(dst.device), "hipSetDevice");
+  if (src.device != dst.device) {   // direct xGMI path between the pair (the copy is staged through the host without it)
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dst.device, src.device) == hipSuccess && can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(src.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) check_hip(e, "hipDeviceEnablePeerAccess");
+      (void)hipGetLastError();
+    }
+  }
+  Batch o;
+  o.nrows = b.nrows; o.on_device = true; o.device_id = dst.device;
+  for (const Column& c : b.cols) {
+    Column cc = c;
+    if (cc.validity && cc.null_count < 0) cc.null_count = 1;   // unknown: keep the bitmap
+    o.cols.push_back(copy_column(dst, cc, Dir::P2P, src.device));
+  }
+  hipEvent_t ev = nullptr;
+  check_hip(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+  const hipError_t e = hipEventRecord(ev, dst.stream);
+  if (e != hipSuccess) { (void)hipEventDestroy(ev); check_hip(e, "hipEventRecord"); }
+  *event_out = ev;
+  return o;
+}
+
 Batch to_host(Context& ctx, const Batch& b) {
   Batch o;
   o.nrows = b.nrows; o.on_device = false; o.device_id = -1;
@@ -403,6 +449,7 @@ namespace {
 
 constexpr int64_t kTileRows[3] = {1024 * 16, 256 * 8, 256 * 8};
 constexpr int kGridPerCu[3] = {1, 4, 4};
+constexpr int kStashSlots[3] = {STASH_SLOTS_K0, STASH_SLOTS_K1, STASH_SLOTS_K2};
 
 struct Scratch {   // header of ctx.small (device) and layout of ctx.pinned (host mirror)
   uint32_t ticket; uint32_t pad0;      // --- [0, kPerPass): re-cleared before every pass of a multi-pass filter
@@ -427,19 +474,116 @@ void ensure_scratch(Context& ctx, int64_t ntiles) {
 Scratch* dev_scratch(Context& ctx) { return (Scratch*)ctx.small->ptr; }
 u64* dev_status(Context& ctx) { return (u64*)((uint8_t*)ctx.small->ptr + kHeader); }
 
+// FAST_UOPS (device_program.h): pre-decode a program whose every instruction works on non-null Int32 / UInt32 / Float32
+// columns, 32-bit literals and boolean temporaries into (operand kind, loop body) pairs.  Returns false -- the generic
+// interpreter runs -- as soon as one instruction falls outside that set.
+bool encode_fast_uops(ProgramBlock& pb, const Lowered& lw, const Batch& rec) {
+  if (lw.wide || lw.num_temps > 0 || !lw.strs.empty() || lw.prog.empty()) return false;
+  auto is32 = [](int t) { return t == T_I32 || t == T_U32 || t == T_F32; };
+  for (int ci : lw.refs) {
+    const Column& c = rec.cols[ci];
+    if (!is32(c.type) || (c.validity && c.null_count != 0)) return false;
+  }
+  for (size_t i = 0; i < lw.prog.size(); ++i) {
+    const Instr& in = pb.prog[i];   // (never modified: incomplete waves run the same program through the generic interpreter)
+    const bool rev = in.flags & IF_REV;
+    uint8_t opd = FO_NONE, fop = FU_NOPS;
+    bool negate = false;
+    // ---- operand ----
+    if (in.src_kind == SRC_COL) {
+      if (!is32(in.src_type)) return false;
+      if (in.src_type == in.type) opd = FO_COL;
+      else if (in.type == T_F32 && in.src_type == T_I32) opd = FO_COL_I2F;
+      else if (in.type == T_F32 && in.src_type == T_U32) opd = FO_COL_U2F;
+      else return false;
+    } else if (in.src_kind == SRC_CONST) {
+      if (!is32(in.type) && !(in.op == OP_LOAD && in.type == T_BOOL)) return false;
+      if (in.type == T_BOOL) return false;   // boolean literals take the generic path (length rules make them rare)
+      opd = FO_CONST;
+    } else if (in.src_kind == SRC_TEMP) {
+      if (in.src_type != T_BOOL || in.src_idx >= MAX_BOOL_TEMPS) return false;
+      opd = FO_BTEMP;
+    }
+    // ---- operation ----
+    const uint32_t c = (uint32_t)in.imm;
+    const bool pow2 = opd == FO_CONST && !rev && c != 0 && c <= 0x40000000u && (c & (c - 1)) == 0;
+    switch (in.op) {
+      case OP_LOAD:
+        if (opd == FO_NONE) return false;
+        if (opd == FO_BTEMP && in.type != T_BOOL) return false;
+        fop = FU_LD;
+        break;
+      case OP_ADD: case OP_MUL: case OP_SUB: case OP_DIV: case OP_REM: {
+        if (opd == FO_BTEMP || opd == FO_NONE) return false;
+        const bool add = in.op == OP_ADD, mul = in.op == OP_MUL, sub = in.op == OP_SUB, div = in.op == OP_DIV;
+        if (in.type == T_F32) {
+          if (add) fop = FU_ADD_F; else if (mul) fop = FU_MUL_F; else if (sub) fop = rev ? FU_RSUB_F : FU_SUB_F;
+          else if (div) fop = rev ? FU_RDIV_F : FU_DIV_F; else return false;   // fmod: generic path
+        } else if (in.type == T_I32 || in.type == T_U32) {
+          const bool s = in.type == T_I32;
+          if (add) fop = s ? FU_ADD_I : FU_ADD_U; else if (mul) fop = s ? FU_MUL_I : FU_MUL_U;
+          else if (sub) fop = rev ? (s ? FU_RSUB_I : FU_RSUB_U) : (s ? FU_SUB_I : FU_SUB_U);
+          else if (pow2) fop = div ? (s ? FU_DIVP2_I : FU_DIVP2_U) : (s ? FU_REMP2_I : FU_REMP2_U);
+          else return false;   // general integer division: generic path
+        } else return false;
+      } break;
+      case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE: {
+        if (opd == FO_BTEMP || opd == FO_NONE || !is32(in.type)) return false;
+        // primitives on (x = accumulator, y = operand): EQ, LT (x < y), GT (x > y); `rev` = operand (op) accumulator
+        bool lt = false;   // else gt
+        switch (in.op) {
+          case OP_EQ: fop = FU_EQ; break;
+          case OP_NE: fop = FU_EQ; negate = true; break;
+          case OP_LT: lt = !rev; fop = 1; break;
+          case OP_GT: lt = rev; fop = 1; break;
+          case OP_LE: lt = rev; negate = true; fop = 1; break;    // x <= y == !(x > y)
+          default: lt = !rev; negate = true; fop = 1; break;      // x >= y == !(x < y)
+        }
+        if (fop == 1) {
+          if (in.type == T_I32) fop = lt ? FU_LT_I : FU_GT_I;
+          else if (in.type == T_U32) fop = lt ? FU_LT_U : FU_GT_U;
+          else if (opd == FO_CONST && (int32_t)c >= 0) fop = lt ? FU_LT_I : FU_GT_I;   // raw bits order like the keys (kernels.hip: run_cmp_const)
+          else if (opd == FO_CONST) fop = lt ? FU_LT_FKC : FU_GT_FKC;   // (the device keys the literal once per instruction)
+          else fop = lt ? FU_LT_F : FU_GT_F;
+        }
+      } break;
+      case OP_AND: case OP_OR:
+        if (opd != FO_BTEMP) return false;
+        fop = in.op == OP_AND ? FU_AND : FU_OR;
+        break;
+      case OP_SPILL:
+        if (in.type != T_BOOL || in.src_idx >= MAX_BOOL_TEMPS) return false;
+        fop = FU_SPILL; opd = FO_NONE;
+        break;
+      case OP_CAST:
+        if (in.type == T_F32 && in.src_type == T_I32) fop = FU_CVT_I2F;
+        else if (in.type == T_F32 && in.src_type == T_U32) fop = FU_CVT_U2F;
+        else return false;
+        opd = FO_NONE;
+        break;
+      case OP_STORE: fop = FU_STORE; opd = FO_NONE; break;
+      default: return false;
+    }
+    pb.fast_op[i] = (uint8_t)(fop | (negate ? FU_NEGATE : 0));
+    pb.fast_opd[i] = opd;
+  }
+  return true;
+}
+
 void fill_refs(ProgramBlock& pb, const Lowered& lw, const Batch& rec, const std::vector<BufferPtr>& str_bufs) {
   pb.n_instr = (int32_t)lw.prog.size();
   pb.n_refs = (int32_t)lw.refs.size();
   pb.fast_kind = FAST_NONE;
-  // [LOAD col:T] [CMP literal] on a non-null 32-bit column of exactly the compare type: specialised device path
-  if (lw.prog.size() == 2 && lw.refs.size() == 1 && lw.prog[0].op == OP_LOAD && lw.prog[0].src_kind == SRC_COL &&
-      lw.prog[0].src_type == lw.prog[0].type && lw.prog[1].op >= OP_EQ && lw.prog[1].op <= OP_GE &&
-      lw.prog[1].src_kind == SRC_CONST && lw.prog[1].type == lw.prog[0].type &&
-      (lw.prog[0].type == T_I32 || lw.prog[0].type == T_U32 || lw.prog[0].type == T_F32)) {
-    const Column& c0 = rec.cols[lw.refs[0]];
-    if (!(c0.validity && c0.null_count != 0)) pb.fast_kind = FAST_CMP_CONST;
-  }
   for (size_t i = 0; i < lw.prog.size(); ++i) pb.prog[i] = lw.prog[i];
+  // Programs over non-null 32-bit columns are pre-decoded for the FASTK kernels (device_program.h); among them the shape
+  // [LOAD col:T] [CMP literal] on a column of exactly the compare type has its own even leaner device path.
+  if (encode_fast_uops(pb, lw, rec)) {
+    pb.fast_kind = FAST_UOPS;
+    if (lw.prog.size() == 2 && lw.refs.size() == 1 && lw.prog[0].op == OP_LOAD && lw.prog[0].src_kind == SRC_COL &&
+        lw.prog[0].src_type == lw.prog[0].type && lw.prog[1].op >= OP_EQ && lw.prog[1].op <= OP_GE &&
+        lw.prog[1].src_kind == SRC_CONST && lw.prog[1].type == lw.prog[0].type)
+      pb.fast_kind = FAST_CMP_CONST;
+  }
   for (size_t i = 0; i < lw.refs.size(); ++i) {
     const Column& c = rec.cols[lw.refs[i]];
     ColRef r{};
@@ -478,6 +622,26 @@ int pick_tile_kind(const Context& ctx, const Lowered& lw, int64_t rows) {
   if (lw.wide || lw.num_temps > 0) return 2;
   if (ctx.opt_tile_kind >= 0) return (int)ctx.opt_tile_kind;
   return rows >= (1 << 18) ? 0 : 1;
+}
+
+bool stashable(const Column& c) { return c.type != T_BOOL && c.type != T_UTF8 && c.width > 0 && c.width <= 4; }
+
+// Up to `slots` narrow predicate input columns stay on chip between the predicate and copy phases (device_program.h:
+// FilterParams::stash_refs); they move to the end of the launch's column order, slot k <-> the k-th of them.
+void pick_stash(FilterParams& p, const Context& ctx, const Lowered& lw, const std::vector<Column>& cols, std::vector<int>& launch_cols, int tile_kind) {
+  const int slots = std::min<int>(kStashSlots[tile_kind], ctx.opt_stash < 0 ? MAX_STASH : (int)ctx.opt_stash);
+  p.n_stash = 0;
+  std::vector<int> chosen;
+  for (size_t r = 0; r < lw.refs.size() && r < 127 && p.n_stash < slots; ++r) {
+    const int ci = lw.refs[r];
+    if ((size_t)ci >= cols.size() || !stashable(cols[ci])) continue;   // (a temporary column is not an output column)
+    if (std::find(chosen.begin(), chosen.end(), ci) != chosen.end()) continue;
+    auto it = std::find(launch_cols.begin(), launch_cols.end(), ci);
+    if (it == launch_cols.end()) continue;
+    launch_cols.erase(it); launch_cols.push_back(ci);
+    chosen.push_back(ci);
+    p.stash_refs[p.n_stash++] = (int8_t)r;
+  }
 }
 
 std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols,
@@ -678,17 +842,9 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     }
     std::vector<int> launch_cols;
     while (next_fixed < fixed_cols.size() && (int)launch_cols.size() < MAX_OUT) launch_cols.push_back(fixed_cols[next_fixed++]);
-    // keep one narrow predicate input column on chip between the predicate and copy phases (placed last)
-    p.stash_ref = -1;
-    if (first && ctx.opt_stash) {
-      for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
-        if ((size_t)lw.refs[r] >= rec.cols.size()) continue;   // a temporary column: not an output column
-        const Column& c = rec.cols[lw.refs[r]];
-        if (c.type == T_BOOL || c.type == T_UTF8 || c.width > 4) continue;
-        auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
-        if (it != launch_cols.end()) { launch_cols.erase(it); launch_cols.push_back(lw.refs[r]); p.stash_ref = (int16_t)r; }
-      }
-    }
+    // narrow predicate input columns stay on chip between the predicate and copy phases (placed last)
+    p.n_stash = 0;
+    if (first) pick_stash(p, ctx, lw, rec.cols, launch_cols, tile_kind);
     int n = 0;
     for (int ci : launch_cols) {
       p.outs[n].in = rec.cols[ci].values0(); p.outs[n].out = (void*)out.cols[ci].values; p.outs[n].width = (uint32_t)rec.cols[ci].width;
@@ -909,14 +1065,7 @@ bool filter_record_small_host(Context& ctx, const Batch& rec, const chq_table_al
   fill_refs(p.pb, lw, dev, {});
   std::vector<int> launch_cols;
   for (size_t i = 0; i < ncols; ++i) launch_cols.push_back((int)i);
-  p.stash_ref = -1;
-  if (ctx.opt_stash) {
-    for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
-      if (rec.cols[lw.refs[r]].width > 4) continue;
-      auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
-      if (it != launch_cols.end()) { launch_cols.erase(it); launch_cols.push_back(lw.refs[r]); p.stash_ref = (int16_t)r; }
-    }
-  }
+  pick_stash(p, ctx, lw, rec.cols, launch_cols, tile_kind);
   int n = 0;
   for (int ci : launch_cols) {
     p.outs[n].in = d_in + at[ci]; p.outs[n].out = d_out + at[ci]; p.outs[n].width = (uint32_t)rec.cols[ci].width;
@@ -1328,15 +1477,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   std::vector<int> launch_cols;
   for (size_t i = 0; i < ncols; ++i) launch_cols.push_back((int)i);
   FilterParams p{};
-  p.stash_ref = -1;
-  if (ctx.opt_stash) {
-    for (size_t r = 0; r < lw.refs.size() && p.stash_ref < 0; ++r) {
-      const Column& c = recs[0].cols[lw.refs[r]];
-      if (c.width > 4) continue;
-      auto it = std::find(launch_cols.begin(), launch_cols.end(), lw.refs[r]);
-      if (it != launch_cols.end()) { launch_cols.erase(it); launch_cols.push_back(lw.refs[r]); p.stash_ref = (int16_t)r; }
-    }
-  }
+  pick_stash(p, ctx, lw, recs[0].cols, launch_cols, tile_kind);
   const size_t nrefs = lw.refs.size(), nout = launch_cols.size();
   const size_t stride = (wpb > 0 ? 1 : 2) + nrefs + nout;
 
@@ -1842,7 +1983,6 @@ bool filter_project_fused(Context& ctx, const Batch& rec, const std::vector<Plan
   p.status = dev_status(ctx); p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
   fill_refs(p.pred, lwp, rec, {});
   fill_refs(p.proj, lwq, rec, {});
-  p.proj.fast_kind = FAST_NONE;
   p.n_proj = (int32_t)computed.size();
   std::vector<char> read_once(rec.cols.size(), 0);
   for (int ci : lwp.refs) read_once[ci] = 1;

@@ -116,7 +116,7 @@ struct Context {
   int64_t opt_tile_kind = -1;       // -1 auto
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
-  bool opt_stash = true;
+  int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots
   int64_t opt_fuse = 1;             // chq_filter_project_record's single-pass kernel: 0 never, 1 when it moves clearly fewer bytes, 2 whenever possible
   int64_t opt_grid_per_cu = 0;
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels
@@ -142,11 +142,15 @@ void check_hip(hipError_t e, const char* what);
 
 // Arrow C Data Interface <-> Batch
 Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema);
-void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema* out_schema);
+// `sync_event`: optional event the consumer must wait on; the exported array owns it (destroyed on release)
+void export_batch(Batch&& b, int device_type, ArrowDeviceArray* out, ArrowSchema* out_schema, hipEvent_t sync_event = nullptr);
 void export_single_column(Column&& c, bool on_device, int device_id, ArrowDeviceArray* out, ArrowSchema* out_schema);
 
 Batch to_device(Context& ctx, const Batch& b);   // stage host batch into HBM (no-op view when already there)
 Batch to_host(Context& ctx, const Batch& b);
+// device batch on src's GPU -> fresh buffers on dst's GPU (hipMemcpyPeerAsync on dst's stream); *event_out receives an
+// event recorded behind the last copy (the caller owns it)
+Batch copy_to_peer(Context& src, Context& dst, const Batch& b, hipEvent_t* event_out);
 
 // the record-level operations (throw ChqError)
 // `split`: optional input-row positions (ascending); on return bounds[i] = selected rows before starts[i], i.e. where the

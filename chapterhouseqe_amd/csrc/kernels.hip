@@ -98,6 +98,51 @@ __device__ __forceinline__ u64 lookback_exclusive(const u64* status, int64_t til
   return excl;
 }
 
+// The wide form: `lookback_issue` loads the status words of the 256 predecessors of `tile` (four per lane, all in flight
+// together), `lookback_resolve` sums them back to the nearest inclusive prefix.  Returns false when a needed word was not
+// published yet (or no inclusive prefix lies within 256 tiles).
+__device__ __forceinline__ void lookback_issue(const u64* status, int64_t tile, int64_t first_tile, int lane, u64 (&w)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t idx = tile - 1 - lane - 64 * k;
+    w[k] = idx >= first_tile ? st_load(&status[idx]) : ST_INC;
+  }
+}
+__device__ __forceinline__ bool lookback_resolve(const u64 (&w)[4], int lane, u64& excl_out) {
+  u64 excl = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u64 incm = __ballot(ST_FLAG(w[k]) == 2), zerom = __ballot(ST_FLAG(w[k]) == 0);
+    if (incm) {
+      const int first = __builtin_ctzll(incm);
+      if (zerom & ((1ULL << first) - 1ULL)) return false;
+      excl += wave_sum((lane <= first) ? ST_VAL(w[k]) : 0ULL);
+      excl_out = excl;
+      return true;
+    }
+    if (zerom) return false;
+    excl += wave_sum(ST_VAL(w[k]));
+  }
+  return false;
+}
+
+// blocking form of the 256-wide look-back: re-reads the window until it resolves; the narrow loop takes over when the
+// nearest inclusive prefix lies further back than the window
+__device__ __forceinline__ u64 lookback_exclusive_wide(const u64* status, int64_t tile, int64_t first_tile, int lane) {
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    u64 w[4];
+    lookback_issue(status, tile, first_tile, lane, w);
+    u64 excl;
+    if (lookback_resolve(w, lane, excl)) return excl;
+    bool all_published = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) all_published = all_published && (__ballot(ST_FLAG(w[k]) == 0) == 0);
+    if (all_published) break;           // 256 aggregates and no inclusive prefix among them: walk further back
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return lookback_exclusive(status, tile, first_tile, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
@@ -165,10 +210,14 @@ __device__ __forceinline__ void int_range(int t, int64_t& lo, int64_t& hi) {
 // only (loops fully unrolled) so they live in VGPRs.  WIDE=false instantiations carry no 64-bit types.
 // ------------------------------------------------------------------------------------------------
 // PARTIAL=false: every wave has all 64*R rows inside the batch (no clamping / masking code is generated at all)
-template <int BLOCK, int R, bool WIDE, bool PARTIAL>
+// NS: predicate input columns (<= 4 bytes wide) whose raw values the filter kernel keeps on chip between its predicate and
+// copy phases: they go to the LDS block `stash_lds` ([NS][R][BLOCK]) while the program fetches column-ref `stash_ref[k]`
+// (0 for every other user of the interpreter).
+template <int BLOCK, int R, bool WIDE, bool PARTIAL, int NS = 0>
 struct Interp {
   static constexpr int NW = BLOCK / 64;
   static constexpr int RH = WIDE ? R : 1;
+  static constexpr int NSA = NS > 0 ? NS : 1;
   static_assert(R <= 32, "slot flags are packed in 32-bit registers");
 
   uint32_t lo[R], hi[RH];
@@ -178,8 +227,9 @@ struct Interp {
   int64_t nrows;
   int nact;          // active rows in [w0, w0 + 64R) (uniform)
   int lane, wv;
-  uint32_t* stash = nullptr;   // LDS [R][BLOCK]: raw values of column-ref `stash_ref`, reused by the copy phase
-  int stash_ref = -1;
+  uint32_t* stash_lds = nullptr;
+  int stash_ref[NSA];
+  int n_stash = 0;
   const u64* ptr_row = nullptr;   // batch-group launch: value pointer of column-ref k is ptr_row[k] (PARTIAL only)
 
   __device__ __forceinline__ void set_rows(int64_t tile_start, int64_t nrows_, int lane_, int wv_) {
@@ -194,6 +244,18 @@ struct Interp {
       actv = 0;
 #pragma unroll
       for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
+    }
+  }
+  __device__ __forceinline__ void stash_put(int ref_idx, const uint32_t (&v)[R]) {
+    if constexpr (NS > 0) {
+      if (n_stash == 0) return;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        if (ref_idx == stash_ref[k]) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) stash_lds[(k * R + j) * BLOCK + wv * 64 + lane] = v[j];
+        }
+      }
     }
   }
   __device__ __forceinline__ u64 group_act(int j) const { return active_mask(w0 + 64 * j, nrows); }
@@ -296,24 +358,35 @@ struct Interp {
   __device__ __forceinline__ void convert(int from_t, int to_t, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b) {
     const int from = vclass(from_t), to = vclass(to_t);
     if (from == to || from == C_BOOL || from == C_NONE) return;
+    // (every wave-uniform choice is made OUTSIDE the slot loops: left inside, the compiler evaluates both sides for
+    // every slot and selects with a v_cndmask)
     if (to == C_BOOL) {
       b = 0;
+      if (from == C_I32 || from == C_U32) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        bool nz;
-        if (from == C_I32 || from == C_U32) nz = l[j] != 0;
-        else if (from == C_F32) nz = __uint_as_float(l[j]) != 0.0f;
-        else if constexpr (WIDE) {
-          if (from == C_F64) nz = __longlong_as_double((long long)PACK64(l[j], h[j])) != 0.0;
-          else nz = (l[j] | h[j]) != 0;
-        } else nz = false;
-        b |= (uint32_t)nz << j;
+        for (int j = 0; j < R; ++j) b |= (uint32_t)(l[j] != 0) << j;
+      } else if (from == C_F32) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) b |= (uint32_t)(__uint_as_float(l[j]) != 0.0f) << j;
+      } else if constexpr (WIDE) {
+        if (from == C_F64) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) b |= (uint32_t)(__longlong_as_double((long long)PACK64(l[j], h[j])) != 0.0) << j;
+        } else {
+#pragma unroll
+          for (int j = 0; j < R; ++j) b |= (uint32_t)((l[j] | h[j]) != 0) << j;
+        }
       }
       return;
     }
-    if (to == C_F32) {
+    if (to == C_F32) {   // round-to-nearest-even
+      if (from == C_I32) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) l[j] = __float_as_uint(from == C_I32 ? (float)(int32_t)l[j] : (float)l[j]);   // round-to-nearest-even
+        for (int j = 0; j < R; ++j) l[j] = __float_as_uint((float)(int32_t)l[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = __float_as_uint((float)l[j]);
+      }
       return;
     }
     if (to == C_I32 || to == C_U32) return;   // u8/u16 -> i32: same bits
@@ -366,69 +439,78 @@ struct Interp {
 #define BAD(code) do { if (live && errj < 0) { errj = j; errc = (code); } } while (0)
     if (cls == C_I32) {
       int64_t tlo, thi; int_range(t, tlo, thi);
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int32_t x = (int32_t)lo[j], y = (int32_t)bl(j);
-        const int32_t a = rev ? y : x, b = rev ? x : y;
-        const bool live = (validv >> j) & 1;
-        int64_t w;
-        switch (op) {
-          case OP_ADD: w = (int64_t)a + b; break;
-          case OP_SUB: w = (int64_t)a - b; break;
-          case OP_MUL: w = (int64_t)a * b; break;
-          case OP_DIV: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (a == INT32_MIN && b == -1) w = 2147483648LL; else w = a / b; break;
-          default: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (b == -1) { if ((int64_t)a == tlo) BAD(DE_OVERFLOW); w = 0; } else w = a % b; break;
-        }
-        if (w < tlo || w > thi) BAD(DE_OVERFLOW);
-        lo[j] = (uint32_t)w;
+      // computed in 64 bits and range-checked against the declared type; operator and operand order are chosen outside
+      // the slot loops (see convert)
+#define I32_LOOP(A, B, BODY)                                                                            \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const int32_t x = (int32_t)lo[j], y = (int32_t)bl(j);                                              \
+      const int32_t a = (A), b = (B);                                                                    \
+      const bool live = (validv >> j) & 1;                                                               \
+      int64_t w;                                                                                         \
+      BODY                                                                                               \
+      if (w < tlo || w > thi) BAD(DE_OVERFLOW);                                                          \
+      lo[j] = (uint32_t)w; } }
+#define I32_DIR(BODY) { if (rev) I32_LOOP(y, x, BODY) else I32_LOOP(x, y, BODY) }
+      switch (op) {
+        case OP_ADD: I32_LOOP(x, y, w = (int64_t)a + b;) break;
+        case OP_MUL: I32_LOOP(x, y, w = (int64_t)a * b;) break;
+        case OP_SUB: I32_DIR(w = (int64_t)a - b;) break;
+        case OP_DIV: I32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (a == INT32_MIN && b == -1) w = 2147483648LL; else w = a / b;) break;
+        default: I32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (b == -1) { if ((int64_t)a == tlo) BAD(DE_OVERFLOW); w = 0; } else w = a % b;) break;
       }
+#undef I32_DIR
+#undef I32_LOOP
     } else if (cls == C_U32) {
       int64_t tlo, thi; int_range(t, tlo, thi);
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const uint32_t x = lo[j], y = bl(j);
-        const uint32_t a = rev ? y : x, b = rev ? x : y;
-        const bool live = (validv >> j) & 1;
-        int64_t w;
-        switch (op) {
-          case OP_ADD: w = (int64_t)a + b; break;
-          case OP_SUB: w = (int64_t)a - b; break;
-          case OP_MUL: { uint64_t pr = (uint64_t)a * b; w = pr > 0x7fffffffffffffffULL ? -1 : (int64_t)pr; } break;
-          case OP_DIV: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a / b; break;
-          default: if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a % b; break;
-        }
-        if (w < tlo || w > thi) BAD(DE_OVERFLOW);
-        lo[j] = (uint32_t)w;
+#define U32_LOOP(A, B, BODY)                                                                            \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const uint32_t x = lo[j], y = bl(j);                                                               \
+      const uint32_t a = (A), b = (B);                                                                   \
+      const bool live = (validv >> j) & 1;                                                               \
+      int64_t w;                                                                                         \
+      BODY                                                                                               \
+      if (w < tlo || w > thi) BAD(DE_OVERFLOW);                                                          \
+      lo[j] = (uint32_t)w; } }
+#define U32_DIR(BODY) { if (rev) U32_LOOP(y, x, BODY) else U32_LOOP(x, y, BODY) }
+      switch (op) {
+        case OP_ADD: U32_LOOP(x, y, w = (int64_t)a + b;) break;
+        case OP_MUL: U32_LOOP(x, y, { uint64_t pr = (uint64_t)a * b; w = pr > 0x7fffffffffffffffULL ? -1 : (int64_t)pr; }) break;
+        case OP_SUB: U32_DIR(w = (int64_t)a - b;) break;
+        case OP_DIV: U32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a / b;) break;
+        default: U32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a % b;) break;
       }
+#undef U32_DIR
+#undef U32_LOOP
     } else if (cls == C_F32) {
-      // +, * and / with a finite non-zero literal cannot be an invalid operation, and a NaN in the other operand is
-      // propagated (quieted) by the hardware exactly as SSE does: no fix-ups needed (`e / 3.0`, `x * 2.0`, `v + 10.0`)
-      bool nan_care = true;
-      if (bconst && op != OP_REM) {
-        const float c = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bl(0)));
-        nan_care = !(c == c && c != 0.0f && fabsf(c) != INFINITY);
+      // One IEEE operation per slot, the operator and operand order decided once outside the slot loop.  Only a NaN
+      // result needs more work, and a wave sees one rarely: the fix-ups sit behind a wave-uniform test per slot.
+      //   an invalid operation on non-NaN inputs (0/0, inf + -inf, 0 * inf, fmod(x, 0)) yields the DEFAULT NaN, whose sign
+      //   is a property of the machine: the reference's hosts (x86-64 SSE) produce 0xFFC00000, gfx950 0x7FC00000.  arrow's
+      //   comparisons are totalOrder, so the sign decides whether `nan < x` holds: follow the reference's host.
+      //   NaN operands: SSE returns the first NaN operand, quieted (glibc's fmod reaches the same value through
+      //   (x * y) / (x * y)); the GPU's fmod and a commuted hardware add / mul may pick the other one or a canonical NaN
+#define F32_LOOP(A, B, EXPR)                                                                            \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const float x = __uint_as_float(lo[j]), y = __uint_as_float(bl(j));                                \
+      const float a = (A), b = (B);                                                                      \
+      float w = (EXPR);                                                                                  \
+      if (__ballot(w != w) != 0) {                                                                       \
+        const float fa = rev ? y : x, fb = rev ? x : y;   /* first / second operand of the SQL expression */ \
+        if (w != w) {                                                                                    \
+          if (fa != fa) w = __uint_as_float(__float_as_uint(fa) | 0x00400000u);                          \
+          else if (fb != fb) w = __uint_as_float(__float_as_uint(fb) | 0x00400000u);                     \
+          else w = __uint_as_float(0xFFC00000u);                                                         \
+        }                                                                                                \
+      }                                                                                                  \
+      lo[j] = __float_as_uint(w); } }
+      switch (op) {   // (`rev` is wave-uniform: each direction of a non-commutative operator is its own straight-line loop)
+        case OP_ADD: F32_LOOP(x, y, a + b) break;
+        case OP_MUL: F32_LOOP(x, y, a * b) break;
+        case OP_SUB: if (rev) F32_LOOP(y, x, a - b) else F32_LOOP(x, y, a - b) break;
+        case OP_DIV: if (rev) F32_LOOP(y, x, a / b) else F32_LOOP(x, y, a / b) break;
+        default: if (rev) F32_LOOP(y, x, fmodf(a, b)) else F32_LOOP(x, y, fmodf(a, b)) break;
       }
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const float x = __uint_as_float(lo[j]), y = __uint_as_float(bl(j));
-        const float a = rev ? y : x, b = rev ? x : y;
-        float w;
-        switch (op) {
-          case OP_ADD: w = a + b; break; case OP_SUB: w = a - b; break; case OP_MUL: w = a * b; break;
-          case OP_DIV: w = a / b; break; default: w = fmodf(a, b); break;
-        }
-        // an invalid operation on non-NaN inputs (0/0, inf + -inf, 0 * inf, fmod(x, 0)) yields the DEFAULT NaN, whose
-        // sign is a property of the machine: the reference's hosts (x86-64 SSE) produce 0xFFC00000, gfx950 0x7FC00000.
-        // arrow's comparisons are totalOrder, so the sign decides whether `nan < x` holds: follow the reference's host.
-        if (nan_care) {
-          if (w != w && a == a && b == b) w = __uint_as_float(0xFFC00000u);
-          // NaN operands: SSE returns the first NaN operand, quieted (glibc's fmod reaches the same value through
-          // (x * y) / (x * y)); the GPU's fmod and a commuted hardware add / mul may pick the other one or a canonical NaN
-          if (a != a) w = __uint_as_float(__float_as_uint(a) | 0x00400000u);
-          else if (b != b) w = __uint_as_float(__float_as_uint(b) | 0x00400000u);
-        }
-        lo[j] = __float_as_uint(w);
-      }
+#undef F32_LOOP
     } else if constexpr (WIDE) {
       if (cls == C_I64) {
 #pragma unroll
@@ -492,7 +574,7 @@ struct Interp {
   }
 
   // ---- comparisons: arrow-ord cmp::*; floats by IEEE totalOrder ------------------------------------
-  __device__ __forceinline__ void compare(int op, int t, bool rev, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], uint32_t bb) {
+  __device__ __forceinline__ void compare(int op, int t, bool rev, bool bconst, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], uint32_t bb) {
     const int cls = vclass(t);
     if (cls == C_BOOL) {
       const uint32_t a = rev ? bb : bitsv, b = rev ? bitsv : bb;
@@ -515,7 +597,16 @@ struct Interp {
   { if (want_eq) { _Pragma("unroll") for (int j = 0; j < R; ++j) { const TY x = (XJ), y = (YJ); r |= (uint32_t)(x == y) << j; } } \
     else if (swap) { _Pragma("unroll") for (int j = 0; j < R; ++j) { const TY x = (XJ), y = (YJ); r |= (uint32_t)(y < x) << j; } }  \
     else { _Pragma("unroll") for (int j = 0; j < R; ++j) { const TY x = (XJ), y = (YJ); r |= (uint32_t)(x < y) << j; } } }
-    if (cls == C_I32) CMP_LOOPS(int32_t, (int32_t)lo[j], (int32_t)bl[j])
+    if (bconst && (cls == C_I32 || cls == C_U32 || cls == C_F32)) {
+      // a literal operand lives in one scalar register; against a Float32 literal with a clear sign bit the raw bit
+      // patterns already order like the totalOrder keys (see run_cmp_const)
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl[0]);
+      if (cls == C_I32) CMP_LOOPS(int32_t, (int32_t)lo[j], (int32_t)c)
+      else if (cls == C_U32) CMP_LOOPS(uint32_t, lo[j], c)
+      else if ((int32_t)c >= 0) CMP_LOOPS(int32_t, (int32_t)lo[j], (int32_t)c)
+      else { const int32_t kc = f32_key(c); CMP_LOOPS(int32_t, f32_key(lo[j]), kc) }
+    }
+    else if (cls == C_I32) CMP_LOOPS(int32_t, (int32_t)lo[j], (int32_t)bl[j])
     else if (cls == C_U32) CMP_LOOPS(uint32_t, lo[j], bl[j])
     else if (cls == C_F32) CMP_LOOPS(int32_t, f32_key(lo[j]), f32_key(bl[j]))   // IEEE totalOrder through the integer key
     else if constexpr (WIDE) {
@@ -558,6 +649,157 @@ struct Interp {
     bitsv = r & actv;
   }
 
+  // ---- the pre-decoded program (device_program.h: FastOp / FastOperand) -----------------------------------------------
+  __device__ __forceinline__ void fetch_raw(const ProgramBlock& pb, int ref_idx, uint32_t (&y)[R]) {
+    const void* vals = (PARTIAL && ptr_row) ? (const void*)ptr_row[ref_idx] : pb.refs[ref_idx].values;
+    if (!PARTIAL || nact == 64 * R) {
+      const uint32_t* src = (const uint32_t*)vals + w0;
+#pragma unroll
+      for (int j = 0; j < R; ++j) y[j] = src[j * 64 + lane];
+    } else {   // incomplete wave: range-checked loads, rows past the end read as 0 (they are inactive: actv masks them)
+      const auto rs = wave_rows_rsrc(vals, w0, 4, nact);
+#pragma unroll
+      for (int j = 0; j < R; ++j) y[j] = nact > 0 ? buf_load<uint32_t>(rs, j * 64 + lane) : 0u;
+    }
+  }
+
+  template <typename StoreFn>
+  __device__ __forceinline__ void run_fast(const ProgramBlock& pb, u64* err, StoreFn&& store) {
+    bitsv = 0; validv = actv;
+    int acc_type = T_BOOL;
+    uint32_t y[R];
+    uint32_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
+    for (int pc = 0; pc < pb.n_instr; ++pc) {
+      const Instr in = pb.prog[pc];
+      const unsigned fop = pb.fast_op[pc] & 0x7fu;
+      const bool neg = (pb.fast_op[pc] & FU_NEGATE) != 0;
+      const unsigned opd = pb.fast_opd[pc];
+      const uint32_t c = (uint32_t)in.imm;
+      uint32_t tb = 0;
+      switch (opd) {   // ---- operand ----
+        case FO_COL: fetch_raw(pb, in.src_idx, y); stash_put((int)in.src_idx, y); break;
+        case FO_COL_I2F:
+          fetch_raw(pb, in.src_idx, y); stash_put((int)in.src_idx, y);
+#pragma unroll
+          for (int j = 0; j < R; ++j) y[j] = __float_as_uint((float)(int32_t)y[j]);
+          break;
+        case FO_COL_U2F:
+          fetch_raw(pb, in.src_idx, y); stash_put((int)in.src_idx, y);
+#pragma unroll
+          for (int j = 0; j < R; ++j) y[j] = __float_as_uint((float)y[j]);
+          break;
+        case FO_CONST:
+#pragma unroll
+          for (int j = 0; j < R; ++j) y[j] = c;
+          break;
+        case FO_BTEMP:
+          switch (in.src_idx) { case 0: tb = tb0; break; case 1: tb = tb1; break; case 2: tb = tb2; break; default: tb = tb3; break; }
+          break;
+        default: break;
+      }
+      int errj = -1; uint32_t errc = 0;
+      uint32_t r = 0;
+#define FAST_F(EXPR, FIRST_IS_ACC)                                                                       \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const float x = __uint_as_float(lo[j]), yy = __uint_as_float(y[j]);                                \
+      float w = (EXPR);                                                                                  \
+      if (__ballot(w != w) != 0) {   /* rare: the x86 NaN rules, see Interp::arith */                   \
+        const float fa = (FIRST_IS_ACC) ? x : yy, fb = (FIRST_IS_ACC) ? yy : x;                          \
+        if (w != w) {                                                                                    \
+          if (fa != fa) w = __uint_as_float(__float_as_uint(fa) | 0x00400000u);                          \
+          else if (fb != fb) w = __uint_as_float(__float_as_uint(fb) | 0x00400000u);                     \
+          else w = __uint_as_float(0xFFC00000u);                                                         \
+        }                                                                                                \
+      }                                                                                                  \
+      lo[j] = __float_as_uint(w); }                                                                      \
+    acc_type = T_F32; }
+#define FAST_I(TY, WEXPR, TLO, THI, T)                                                                   \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const TY x = (TY)lo[j], yy = (TY)y[j];                                                             \
+      const int64_t w = (WEXPR);                                                                         \
+      if ((w < (TLO) || w > (THI)) && ((actv >> j) & 1) && errj < 0) { errj = j; errc = DE_OVERFLOW; }   \
+      lo[j] = (uint32_t)w; }                                                                             \
+    acc_type = (T); }
+#define FAST_CMP(COND) { _Pragma("unroll") for (int j = 0; j < R; ++j) r |= (uint32_t)(COND) << j; bitsv = (neg ? ~r : r) & actv; acc_type = T_BOOL; }
+      switch (fop) {   // ---- operation ----
+        case FU_LD:
+          if (opd == FO_BTEMP) { bitsv = tb; acc_type = T_BOOL; }
+          else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) lo[j] = y[j];
+            acc_type = in.type;
+          }
+          break;
+        case FU_ADD_F: FAST_F(x + yy, !(in.flags & IF_REV)) break;
+        case FU_MUL_F: FAST_F(x * yy, !(in.flags & IF_REV)) break;
+        case FU_SUB_F: FAST_F(x - yy, true) break;
+        case FU_RSUB_F: FAST_F(yy - x, false) break;
+        case FU_DIV_F: FAST_F(x / yy, true) break;
+        case FU_RDIV_F: FAST_F(yy / x, false) break;
+        case FU_ADD_I: FAST_I(int32_t, (int64_t)x + yy, (int64_t)INT32_MIN, (int64_t)INT32_MAX, T_I32) break;
+        case FU_SUB_I: FAST_I(int32_t, (int64_t)x - yy, (int64_t)INT32_MIN, (int64_t)INT32_MAX, T_I32) break;
+        case FU_RSUB_I: FAST_I(int32_t, (int64_t)yy - x, (int64_t)INT32_MIN, (int64_t)INT32_MAX, T_I32) break;
+        case FU_MUL_I: FAST_I(int32_t, (int64_t)x * yy, (int64_t)INT32_MIN, (int64_t)INT32_MAX, T_I32) break;
+        case FU_ADD_U: FAST_I(uint32_t, (int64_t)x + yy, 0, 4294967295LL, T_U32) break;
+        case FU_SUB_U: FAST_I(uint32_t, (int64_t)x - yy, 0, 4294967295LL, T_U32) break;
+        case FU_RSUB_U: FAST_I(uint32_t, (int64_t)yy - x, 0, 4294967295LL, T_U32) break;
+        case FU_MUL_U: FAST_I(uint32_t, ((uint64_t)x * yy > 0x7fffffffffffffffULL ? -1 : (int64_t)((uint64_t)x * yy)), 0, 4294967295LL, T_U32) break;
+        case FU_DIVP2_I: case FU_REMP2_I: {   // truncating division by 2^k (arrow div / rem: sign of the dividend)
+          const int k = __builtin_ctz(c);
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const int32_t x = (int32_t)lo[j];
+            const int32_t q = (x + ((x >> 31) & (int32_t)(c - 1))) >> k;
+            lo[j] = fop == FU_DIVP2_I ? (uint32_t)q : (uint32_t)(x - (int32_t)((uint32_t)q << k));
+          }
+          acc_type = T_I32;
+        } break;
+        case FU_DIVP2_U: {
+          const int k = __builtin_ctz(c);
+#pragma unroll
+          for (int j = 0; j < R; ++j) lo[j] = lo[j] >> k;
+          acc_type = T_U32;
+        } break;
+        case FU_REMP2_U:
+#pragma unroll
+          for (int j = 0; j < R; ++j) lo[j] = lo[j] & (c - 1);
+          acc_type = T_U32;
+          break;
+        case FU_EQ: FAST_CMP(lo[j] == y[j]) break;
+        case FU_LT_I: FAST_CMP((int32_t)lo[j] < (int32_t)y[j]) break;
+        case FU_GT_I: FAST_CMP((int32_t)lo[j] > (int32_t)y[j]) break;
+        case FU_LT_U: FAST_CMP(lo[j] < y[j]) break;
+        case FU_GT_U: FAST_CMP(lo[j] > y[j]) break;
+        case FU_LT_F: FAST_CMP(f32_key(lo[j]) < f32_key(y[j])) break;
+        case FU_GT_F: FAST_CMP(f32_key(lo[j]) > f32_key(y[j])) break;
+        case FU_LT_FKC: { const int32_t kc = f32_key(c); FAST_CMP(f32_key(lo[j]) < kc) } break;
+        case FU_GT_FKC: { const int32_t kc = f32_key(c); FAST_CMP(f32_key(lo[j]) > kc) } break;
+        case FU_AND: bitsv &= tb; break;
+        case FU_OR: bitsv |= tb; break;
+        case FU_SPILL:
+          switch (in.src_idx) { case 0: tb0 = bitsv; break; case 1: tb1 = bitsv; break; case 2: tb2 = bitsv; break; default: tb3 = bitsv; break; }
+          break;
+        case FU_CVT_I2F:
+#pragma unroll
+          for (int j = 0; j < R; ++j) lo[j] = __float_as_uint((float)(int32_t)lo[j]);
+          acc_type = T_F32;
+          break;
+        case FU_CVT_U2F:
+#pragma unroll
+          for (int j = 0; j < R; ++j) lo[j] = __float_as_uint((float)lo[j]);
+          acc_type = T_F32;
+          break;
+        case FU_STORE: store(in.src_idx, acc_type, *this); break;
+        default: break;
+      }
+#undef FAST_CMP
+#undef FAST_I
+#undef FAST_F
+      // arrow's try_binary stops at the first offending element: report (node, row, kind) -- as Interp::arith does
+      if (__any(errj >= 0)) { if (errj >= 0) report_error(err, in.ref_order, w0 + 64 * errj + lane, errc); }
+    }
+  }
+
   // ---- specialised shape: 32-bit column <cmp> literal (FAST_CMP_CONST), complete waves only ------------------
   __device__ __forceinline__ void run_cmp_const(const ProgramBlock& pb) {
     const Instr cmp = pb.prog[1];
@@ -565,10 +807,7 @@ struct Interp {
     uint32_t v[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) v[j] = src[j * 64 + lane];
-    if (stash) {
-#pragma unroll
-      for (int j = 0; j < R; ++j) stash[j * BLOCK + wv * 64 + lane] = v[j];
-    }
+    stash_put(0, v);
     const int op = cmp.op;
     const bool rev = cmp.flags & IF_REV;
     const bool want_eq = op == OP_EQ || op == OP_NE;
@@ -584,7 +823,12 @@ struct Interp {
     switch (cmp.type) {
       case T_I32: FAST_LOOPS(int32_t, (int32_t)v[j], (int32_t)c) break;
       case T_U32: FAST_LOOPS(uint32_t, v[j], c) break;
-      default: FAST_LOOPS(int32_t, f32_key(v[j]), f32_key(c)) break;   // T_F32, IEEE totalOrder
+      default:   // T_F32, IEEE totalOrder.  Against a literal with a clear sign bit the raw bit patterns already compare
+                 // like the totalOrder keys: the key of a value with the sign bit set stays negative, every other key is
+                 // the value's own bit pattern
+        if ((int32_t)c >= 0) FAST_LOOPS(int32_t, (int32_t)v[j], (int32_t)c)
+        else FAST_LOOPS(int32_t, f32_key(v[j]), f32_key(c))
+        break;
     }
 #undef FAST_LOOPS
     bitsv = (negate ? ~r : r) & actv;
@@ -608,20 +852,14 @@ struct Interp {
       const uint32_t cl = (uint32_t)in.imm, ch = (uint32_t)(in.imm >> 32);
       if (in.op == OP_LOAD && in.src_kind == SRC_COL) {   // straight into the accumulator
         fetch_col(pb.refs[in.src_idx], in.src_idx, lo, hi, bitsv, validv);
-        if (stash && (int)in.src_idx == stash_ref) {
-#pragma unroll
-          for (int j = 0; j < R; ++j) stash[j * BLOCK + tix] = lo[j];
-        }
+        stash_put((int)in.src_idx, lo);
         convert(in.src_type, in.type, lo, hi, bitsv);
         acc_type = in.type;
         continue;
       }
       if (in.src_kind == SRC_COL) {
         fetch_col(pb.refs[in.src_idx], in.src_idx, bl, bh, bb, bv);
-        if (stash && (int)in.src_idx == stash_ref) {
-#pragma unroll
-          for (int j = 0; j < R; ++j) stash[j * BLOCK + tix] = bl[j];
-        }
+        stash_put((int)in.src_idx, bl);
         if (in.op != OP_STRCMP) convert(in.src_type, in.type, bl, bh, bb);
       } else if (bconst) {   // all slots hold the same value: after unrolling the compiler keeps one copy
 #pragma unroll
@@ -662,7 +900,7 @@ struct Interp {
           break;
         case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE:
           validv &= bv;
-          compare(in.op, in.type, rev, bl, bh, bb);
+          compare(in.op, in.type, rev, bconst, bl, bh, bb);
           acc_type = T_BOOL;
           break;
         case OP_AND: bitsv &= bb; validv &= bv; break;
@@ -720,8 +958,12 @@ struct TempLds {
 // successors' look-backs need it.  Everything a wave derives from the tile index / tile base goes through
 // readfirstlane so that global accesses are SGPR-base + 32-bit lane offset.
 // ------------------------------------------------------------------------------------------------
-template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL>
+// FASTK: the instantiation for pre-decoded programs (FAST_UOPS / FAST_CMP_CONST); it does not contain the generic
+// interpreter at all, and the generic instantiation does not contain the fast evaluators -- one evaluator per kernel keeps
+// each of them inside the register budget.
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL, int NS, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams p) {
+  using I = Interp<BLOCK, R, WIDE, PARTIAL, NS>;
   constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
   __shared__ uint32_t s_sel[2][BLOCK];       // bit j of word t: row (wave, slot j, lane) of thread t is selected
@@ -730,22 +972,26 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
   __shared__ int64_t s_tile[2];
   __shared__ u64 s_base;
   __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
-  // One predicate input column (<= 4 bytes wide) that is also an output column stays on chip between P(i) and
-  // C(i): by the time C(i) runs (a whole tile later) it has left L2, re-reading it costs 4 B/row of HBM traffic
-  // (measured: 16.0 GB fetched instead of 12.0 GB for config 2).
-  __shared__ uint32_t s_stash[2][R * BLOCK];
+  // Up to NS predicate input columns (<= 4 bytes wide) that are also output columns stay on chip between P(i) and
+  // C(i): by the time C(i) runs (a whole tile later) they have left L2, re-reading one costs 4 B/row of HBM traffic
+  // (measured: 16.0 GB fetched instead of 12.0 GB for config 2).  Double buffered -- P(i+1) fills one buffer while
+  // C(i) drains the other -- so the 160 KiB of a CU take one 4-byte column of a 16 384-row tile (two of a 2 048-row
+  // tile).  Measured dead ends for more (round 2): a single-buffered stash whose values wait in
+  // registers across C(i) spills, and 8 192-row tiles with four stashed columns lose more to per-tile costs than the
+  // re-reads cost.
+  __shared__ uint32_t s_stash[2][NS * R * BLOCK];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t ntiles = p.tile_end;                       // this launch: tiles [tile_begin, tile_end)
   const int64_t last_tile = (p.nrows + TILE - 1) / TILE - 1;   // of the whole batch
 
-  auto P = [&](int buf) {
+  auto P = [&](int buf) __attribute__((always_inline)) {   // (two call sites: an outlined copy would take the 2.4 KB parameter block through scratch)
     if (tid == 0) s_tile[buf] = p.tile_begin + (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const int64_t tile = uniform64(s_tile[buf]);
     if (tile >= ntiles) return;
-    Interp<BLOCK, R, WIDE, PARTIAL> it;
+    I it;
     int64_t row0 = tile * TILE, nr = p.nrows;
     if constexpr (PARTIAL) {
       if (p.group_wpb > 0) {   // batch-group launch, wave-granular: this wave's batch and its rows inside it
@@ -765,9 +1011,14 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
       }
     }
     it.set_rows(row0, nr, lane, wv);
-    if (p.stash_ref >= 0) { it.stash = s_stash[buf]; it.stash_ref = p.stash_ref; }
-    if (p.pb.fast_kind == FAST_CMP_CONST && it.nact == 64 * R) it.run_cmp_const(p.pb);
-    else it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, Interp<BLOCK, R, WIDE, PARTIAL>&) {});
+    it.n_stash = p.n_stash;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) it.stash_ref[k] = k < p.n_stash ? (int)p.stash_refs[k] : -1;
+    it.stash_lds = s_stash[buf];
+    if constexpr (FASTK) {
+      if (p.pb.fast_kind == FAST_CMP_CONST && it.nact == 64 * R) it.run_cmp_const(p.pb);
+      else it.run_fast(p.pb, p.err, [](int, int, I&) {});
+    } else it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [](int, int, I&) {});
     const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
     s_sel[buf][tid] = selv;
     if (p.sel_mask) {
@@ -792,7 +1043,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     }
   };
 
-  auto C = [&](int buf) {
+  auto C = [&](int buf) __attribute__((always_inline)) {
     const int64_t tile = uniform64(s_tile[buf]);
     if (wv == 0) {
       u64 excl = 0;
@@ -848,7 +1099,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         run += __popcll(m);
       }
     }
-    const int ncopy = p.stash_ref >= 0 ? p.n_out - 1 : p.n_out;   // the stashed column is outs[n_out-1]
+    const int ncopy = p.n_out - p.n_stash;   // the stashed columns are outs[ncopy .. n_out)
     auto copy_columns = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
       for (int c = 0; c < ncopy; ++c) {
@@ -927,9 +1178,11 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
       if (nact == 64 * R) copy_columns(std::true_type{});   // complete wave: unclamped, immediate-offset loads
       else copy_columns(std::false_type{});
     } else copy_columns(std::true_type{});
-    if (p.stash_ref >= 0) {   // the predicate column: values are still in LDS
-      const OutCol oc = p.outs[p.n_out - 1];
-      const uint32_t* sv = s_stash[buf] + tid;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {   // the stashed predicate columns: values are still in LDS
+      if (k >= p.n_stash) break;
+      const OutCol oc = p.outs[ncopy + k];
+      const uint32_t* sv = s_stash[buf] + k * R * BLOCK + tid;
       unsigned run = 0;
 #define COPY_STASH(TY)                                                                                \
   { TY* dst = (TY*)oc.out + off0;                                                                     \
@@ -964,7 +1217,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 // Any error word set by either phase makes the host discard the result and take the two-call path, which reports
 // the reference's error (predicate errors first, then the select items in order).
 // ------------------------------------------------------------------------------------------------
-template <int BLOCK, int R, bool WIDE, int NUM_TEMPS>
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams p) {
   constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
@@ -981,15 +1234,17 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
   const int64_t ntiles = p.tile_end;
   const int64_t last_tile = (p.nrows + TILE - 1) / TILE - 1;
 
-  auto P = [&](int buf) {
+  auto P = [&](int buf) __attribute__((always_inline)) {
     if (tid == 0) s_tile[buf] = p.tile_begin + (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const int64_t tile = uniform64(s_tile[buf]);
     if (tile >= ntiles) return;
     I it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
-    if (p.pred.fast_kind == FAST_CMP_CONST && it.nact == 64 * R) it.run_cmp_const(p.pred);
-    else it.run(p.pred, p.err, s_tmp.flags, s_tmp.num, [](int, int, I&) {});
+    if constexpr (FASTK) {
+      if (p.pred.fast_kind == FAST_CMP_CONST && it.nact == 64 * R) it.run_cmp_const(p.pred);
+      else it.run_fast(p.pred, p.err, [](int, int, I&) {});
+    } else it.run(p.pred, p.err, s_tmp.flags, s_tmp.num, [](int, int, I&) {});
     const uint32_t selv = it.bitsv & it.validv;
     s_sel[buf][tid] = selv;
     unsigned cnt = __popc(selv);
@@ -1007,7 +1262,7 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
     }
   };
 
-  auto C = [&](int buf) {
+  auto C = [&](int buf) __attribute__((always_inline)) {
     const int64_t tile = uniform64(s_tile[buf]);
     if (wv == 0) {
       u64 excl = 0;
@@ -1055,7 +1310,7 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
     // ---- computed select items ----------------------------------------------------------------------------
     if (p.n_proj > 0) {
       it.actv &= selv;
-      it.run(p.proj, p.err, s_tmp.flags, s_tmp.num, [&](int out_idx, int acc_type, I& s) {
+      auto compact_store = [&](int out_idx, int acc_type, I& s) {
         const ProjOut po = p.outs[out_idx];
         unsigned run = 0;
 #define CSTORE(TY, EXPR)                                                                              \
@@ -1072,7 +1327,9 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
           default: if constexpr (WIDE) CSTORE(uint2, make_uint2(s.lo[j], s.hi[j])) break;
         }
 #undef CSTORE
-      });
+      };
+      if constexpr (FASTK) it.run_fast(p.proj, p.err, compact_store);
+      else it.run(p.proj, p.err, s_tmp.flags, s_tmp.num, compact_store);
     }
   };
 
@@ -1090,7 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
 // ------------------------------------------------------------------------------------------------
 // project_kernel: evaluate every SelectItem expression densely (no compaction, no inter-tile state)
 // ------------------------------------------------------------------------------------------------
-template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL>
+template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
   constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
@@ -1100,7 +1357,7 @@ __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
   for (int64_t tile = p.tile_begin + blockIdx.x; tile < p.tile_end; tile += gridDim.x) {
     Interp<BLOCK, R, WIDE, PARTIAL> it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
-    it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, [&](int out_idx, int acc_type, Interp<BLOCK, R, WIDE, PARTIAL>& s) {
+    auto dense_store = [&](int out_idx, int acc_type, Interp<BLOCK, R, WIDE, PARTIAL>& s) {
       const ProjOut po = p.outs[out_idx];
       if (s.nact <= 0) return;
       const int cls = vclass(acc_type);
@@ -1132,7 +1389,9 @@ __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
         }
         if (nulls && lane == 0) atomicAdd(po.null_count, (u64)nulls);
       }
-    });
+    };
+    if constexpr (FASTK) it.run_fast(p.pb, p.err, dense_store);
+    else it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, dense_store);
     __syncthreads();   // temporaries in LDS are reused by the next tile
   }
 }
@@ -1486,36 +1745,47 @@ __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (extern, used by engine.cpp)
 // ------------------------------------------------------------------------------------------------
-// tile_kind 0: 1024 threads x 16 rows, 32-bit types only, no numeric temporaries (the streaming path)
-// tile_kind 1:  256 threads x  8 rows, 32-bit types only
-// tile_kind 2:  256 threads x  8 rows, all types, numeric temporaries in LDS (general path)
+// tile_kind 0: 1024 threads x 16 rows, 32-bit types only, no numeric temporaries (the streaming path), 1 stash slot
+// tile_kind 1:  256 threads x  8 rows, 32-bit types only, 2 stash slots
+// tile_kind 2:  256 threads x  8 rows, all types, numeric temporaries in LDS (general path), 1 stash slot
 // partial: the launch may contain a tile that is not completely inside the batch
+// The FASTK instantiations serve the pre-decoded programs (32-bit types only: tile kinds 0 and 1), the others the generic
+// interpreter.
 hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
-#define LF(B, RR, W, T) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, true>), dim3(grid), dim3(B), 0, stream, p); \
-                             else hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, false>), dim3(grid), dim3(B), 0, stream, p); } while (0)
+  const bool fast = p.pb.fast_kind != FAST_NONE && tile_kind != 2;
+#define LF(B, RR, W, T, S, F) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, true, S, F>), dim3(grid), dim3(B), 0, stream, p); \
+                                   else hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, false, S, F>), dim3(grid), dim3(B), 0, stream, p); } while (0)
   switch (tile_kind) {
-    case 0: LF(1024, 16, false, 0); break;
-    case 1: LF(256, 8, false, 0); break;
-    default: LF(256, 8, true, MAX_NUM_TEMPS); break;
+    case 0: if (fast) LF(1024, 16, false, 0, STASH_SLOTS_K0, true); else LF(1024, 16, false, 0, STASH_SLOTS_K0, false); break;
+    case 1: if (fast) LF(256, 8, false, 0, STASH_SLOTS_K1, true); else LF(256, 8, false, 0, STASH_SLOTS_K1, false); break;
+    default: LF(256, 8, true, MAX_NUM_TEMPS, STASH_SLOTS_K2, false); break;
   }
 #undef LF
   return hipGetLastError();
 }
 hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, hipStream_t stream) {
+  const bool fast = tile_kind != 2 && p.pred.fast_kind != FAST_NONE && (p.n_proj == 0 || p.proj.fast_kind == FAST_UOPS);
   switch (tile_kind) {
-    case 0: hipLaunchKernelGGL((filter_project_kernel<1024, 16, false, 0>), dim3(grid), dim3(1024), 0, stream, p); break;
-    case 1: hipLaunchKernelGGL((filter_project_kernel<256, 8, false, 0>), dim3(grid), dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL((filter_project_kernel<256, 8, true, MAX_NUM_TEMPS>), dim3(grid), dim3(256), 0, stream, p); break;
+    case 0:
+      if (fast) hipLaunchKernelGGL((filter_project_kernel<1024, 16, false, 0, true>), dim3(grid), dim3(1024), 0, stream, p);
+      else hipLaunchKernelGGL((filter_project_kernel<1024, 16, false, 0, false>), dim3(grid), dim3(1024), 0, stream, p);
+      break;
+    case 1:
+      if (fast) hipLaunchKernelGGL((filter_project_kernel<256, 8, false, 0, true>), dim3(grid), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL((filter_project_kernel<256, 8, false, 0, false>), dim3(grid), dim3(256), 0, stream, p);
+      break;
+    default: hipLaunchKernelGGL((filter_project_kernel<256, 8, true, MAX_NUM_TEMPS, false>), dim3(grid), dim3(256), 0, stream, p); break;
   }
   return hipGetLastError();
 }
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
-#define LP(B, RR, W, T) do { if (partial) hipLaunchKernelGGL((project_kernel<B, RR, W, T, true>), dim3(grid), dim3(B), 0, stream, p); \
-                             else hipLaunchKernelGGL((project_kernel<B, RR, W, T, false>), dim3(grid), dim3(B), 0, stream, p); } while (0)
+  const bool fast = p.pb.fast_kind == FAST_UOPS && tile_kind != 2;
+#define LP(B, RR, W, T, F) do { if (partial) hipLaunchKernelGGL((project_kernel<B, RR, W, T, true, F>), dim3(grid), dim3(B), 0, stream, p); \
+                                else hipLaunchKernelGGL((project_kernel<B, RR, W, T, false, F>), dim3(grid), dim3(B), 0, stream, p); } while (0)
   switch (tile_kind) {
-    case 0: LP(1024, 16, false, 0); break;
-    case 1: LP(256, 8, false, 0); break;
-    default: LP(256, 8, true, MAX_NUM_TEMPS); break;
+    case 0: if (fast) LP(1024, 16, false, 0, true); else LP(1024, 16, false, 0, false); break;
+    case 1: if (fast) LP(256, 8, false, 0, true); else LP(256, 8, false, 0, false); break;
+    default: LP(256, 8, true, MAX_NUM_TEMPS, false); break;
   }
 #undef LP
   return hipGetLastError();

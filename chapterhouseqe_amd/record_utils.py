@@ -234,6 +234,17 @@ class DeviceRecordBatch:
             raise ChqError(rc, self.ctx.last_error())
         return _import_host(out)
 
+    def copy_to_peer(self, dst_ctx: Context) -> "DeviceRecordBatch":
+        """`chq_record_copy_to_peer`: this batch in the HBM of `dst_ctx`'s GPU (hipMemcpyPeerAsync over the xGMI link of
+        the pair, asynchronous: the result carries a sync_event every chq call waits on).  Keep `self` alive until the
+        result has been used once."""
+        out = _CBatch()
+        rc = L.lib().chq_record_copy_to_peer(self.ctx.handle, dst_ctx.handle, C.byref(self._cb.array), C.byref(self._cb.schema),
+                                             C.byref(out.array), C.byref(out.schema))
+        if rc:
+            raise ChqError(rc, dst_ctx.last_error())
+        return DeviceRecordBatch(dst_ctx, out, keepalive=self)
+
     def release(self) -> None:
         self._cb.release()
 

@@ -212,6 +212,21 @@ chq_status chq_record_to_device(chq_ctx* ctx, const struct ArrowDeviceArray* rec
 chq_status chq_record_to_host(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
                               struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
 
+/* The data-plane half of the exchange step, GPU to GPU: copy a batch that lives in the HBM of `src_ctx`'s device into
+ * the HBM of `dst_ctx`'s device with hipMemcpyPeerAsync -- peer to peer over the xGMI link of the pair, no host staging,
+ * no collective.  This is what moves a record when the DAG puts its consumer on another GPU (one filter instance per
+ * GPU feeding one materialize instance) for a worker that runs several operator instances in ONE process
+ * (src/worker/query_worker.rs:35-39), one chq_ctx per GPU.  The reference's exchange semantics are the caller's and do
+ * not change: the record keeps its record_id and table_aliases, the inbound exchange is acked only after the copy was
+ * handed over (exchange_operator.rs:621-667, requests/send_record_request.rs:33-104).
+ * The copies are enqueued on dst_ctx's stream; the call returns without waiting for them.  out->sync_event points to a
+ * hipEvent_t (owned by `out`, destroyed by its release callback) recorded behind the last copy: every chq call that takes
+ * `out` as input waits on it, any other consumer must (Arrow C Device Data Interface).  `rec` must stay alive until that
+ * event has completed.  src_ctx == dst_ctx's device is allowed (a device-local deep copy). */
+chq_status chq_record_copy_to_peer(chq_ctx* src_ctx, chq_ctx* dst_ctx, const struct ArrowDeviceArray* rec,
+                                   const struct ArrowSchema* schema, struct ArrowDeviceArray* out,
+                                   struct ArrowSchema* out_schema);
+
 /* Wrap caller-owned device (or host) buffers as a record batch without copying; the buffers must
  * outlive the returned structs, whose release callbacks free only the descriptors. `format` is an
  * Arrow C format string ("i","f","g","l","b","u", ...). */
