@@ -45,12 +45,46 @@ pub struct chq_table_aliases {
     pub n_columns: c_int,
 }
 
+/// struct chq_call_stats
+#[repr(C)]
+#[derive(Debug, Default, Clone, Copy)]
+pub struct chq_call_stats {
+    pub rows_in: i64,
+    pub rows_out: i64,
+    pub tiles: i64,
+    pub launches: i64,
+    pub bytes_read_alg: i64,
+    pub bytes_written_alg: i64,
+    pub kernel_ns: i64,
+}
+
+/// struct chq_column_desc (chq_wrap_columns)
+#[repr(C)]
+pub struct chq_column_desc {
+    pub name: *const c_char,
+    pub format: *const c_char,
+    pub nullable: c_int,
+    pub null_count: i64,
+    pub offset: i64,
+    pub validity: *const c_void,
+    pub values: *const c_void,
+    pub data: *const c_void,
+}
+
+// Every function include/chq.h declares, in header order (tests/test_abi.py checks names and arity against the header).
 #[link(name = "chq")]
 extern "C" {
+    // ---- context ----
     pub fn chq_ctx_create(device_id: c_int, hip_stream: *mut c_void, out: *mut *mut chq_ctx) -> c_int;
     pub fn chq_ctx_destroy(ctx: *mut chq_ctx);
     pub fn chq_ctx_last_error(ctx: *const chq_ctx) -> *const c_char;
+    pub fn chq_ctx_stream(ctx: *const chq_ctx) -> *mut c_void;
+    pub fn chq_ctx_set_option(ctx: *mut chq_ctx, key: *const c_char, value: i64) -> c_int;
+    pub fn chq_ctx_last_stats(ctx: *const chq_ctx, out: *mut chq_call_stats);
+    pub fn chq_abi_version() -> c_int;
+    pub fn chq_status_name(s: c_int) -> *const c_char;
 
+    // ---- sqlparser::ast::Expr ----
     pub fn chq_expr_identifier(name: *const c_char) -> *mut chq_expr;
     pub fn chq_expr_compound_identifier(parts: *const *const c_char, n: c_int) -> *mut chq_expr;
     pub fn chq_expr_number(text: *const c_char, is_long: c_int) -> *mut chq_expr;
@@ -62,6 +96,7 @@ extern "C" {
     pub fn chq_expr_unsupported(debug: *const c_char) -> *mut chq_expr;
     pub fn chq_expr_free(e: *mut chq_expr);
 
+    // ---- the path ----
     pub fn chq_filter_record(
         ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
         table_aliases: *const chq_table_aliases, expr: *const chq_expr, out_device: c_int,
@@ -82,6 +117,42 @@ extern "C" {
     pub fn chq_project_record(
         ctx: *mut chq_ctx, fields: *const chq_select_item, n_fields: c_int, rec: *const ArrowDeviceArray,
         schema: *const FFI_ArrowSchema, table_aliases: *const chq_table_aliases, out_device: c_int,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+    pub fn chq_compute_value(
+        ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
+        table_aliases: *const chq_table_aliases, expr: *const chq_expr, out_device: c_int,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema, out_is_scalar: *mut c_int,
+    ) -> c_int;
+    /// filter_record followed by project_record on the survivors, one pass (filter_task.rs:99 + materialize_files_task.rs:110)
+    pub fn chq_filter_project_record(
+        ctx: *mut chq_ctx, predicate: *const chq_expr, fields: *const chq_select_item, n_fields: c_int,
+        rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema, table_aliases: *const chq_table_aliases,
+        out_device: c_int, out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+
+    // ---- host half only ----
+    pub fn chq_plan_describe(
+        schema: *const FFI_ArrowSchema, table_aliases: *const chq_table_aliases, expr: *const chq_expr,
+        n_rows: i64, enable_minus: c_int, buf: *mut c_char, buf_len: usize,
+    ) -> c_int;
+
+    // ---- device residency / exchange data plane ----
+    pub fn chq_record_to_device(
+        ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+    pub fn chq_record_to_host(
+        ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+    /// HBM of src_ctx's GPU -> HBM of dst_ctx's GPU over xGMI (hipMemcpyPeerAsync); `out.sync_event` must be waited on
+    pub fn chq_record_copy_to_peer(
+        src_ctx: *mut chq_ctx, dst_ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+    pub fn chq_wrap_columns(
+        ctx: *mut chq_ctx, cols: *const chq_column_desc, n_cols: c_int, n_rows: i64, device_type: c_int,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
     ) -> c_int;
 }

@@ -20,6 +20,59 @@ def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(_lib.EXPORTED_SYMBOLS)
 
 
+def _split_params(text):
+    """top-level comma split of a parameter list ("void" / "" = no parameters)"""
+    text = text.strip()
+    if text in ("", "void"):
+        return []
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "(<[":
+            depth += 1
+        elif ch in ")>]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur.strip())
+    return parts
+
+
+def test_rust_ffi_declares_every_export_with_the_same_arity():
+    """rust/chq_sys.rs (the binding a maintainer drops into the reference) cannot be compiled here: keep it
+    honest by parsing it -- every function of include/chq.h must be declared, with the same number of parameters, and
+    nothing else."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "chq.h")).read(), flags=re.S)
+    c_funcs = {m.group(1): len(_split_params(m.group(2)))
+               for m in re.finditer(r"\b(chq_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)}
+    rust = open(os.path.join(ROOT, "rust", "chq_sys.rs")).read()
+    rust = re.sub(r"//[^\n]*", "", rust)
+    r_funcs = {m.group(1): len(_split_params(m.group(2)))
+               for m in re.finditer(r"pub fn (chq_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*(?:->[^;]*)?;", rust, flags=re.S)}
+    assert sorted(c_funcs) == _declared_symbols()
+    assert sorted(r_funcs) == sorted(c_funcs), (sorted(set(c_funcs) - set(r_funcs)), sorted(set(r_funcs) - set(c_funcs)))
+    for name, n in c_funcs.items():
+        assert r_funcs[name] == n, (name, n, r_funcs[name])
+    # the repr(C) structs the functions take by pointer
+    for struct in ("ArrowDeviceArray", "chq_select_item", "chq_alias_list", "chq_table_aliases", "chq_call_stats", "chq_column_desc"):
+        assert re.search(r"#\[repr\(C\)\]\s*(?:#\[[^\]]*\]\s*)*pub struct " + struct + r"\b", rust), struct
+
+
+def test_rust_task_builders_implement_the_plugin_trait():
+    """the two GPU tasks are complete files: a struct, `impl TaskBuilder for ...` with the trait's seven parameters
+    (operators/traits.rs:22-36) and a MessageConsumer"""
+    for fname, builder in (("gpu_filter_task.rs", "GpuFilterTaskBuilder"), ("gpu_materialize_files_task.rs", "GpuMaterializeFilesTaskBuilder")):
+        text = open(os.path.join(ROOT, "rust", fname)).read()
+        assert f"pub struct {builder}" in text and f"impl TaskBuilder for {builder}" in text, fname
+        m = re.search(r"fn build\(\s*&self,(.*?)\)\s*->", text, flags=re.S)
+        assert m and len(_split_params(m.group(1))) == 7, fname
+        assert "tt.spawn(" in text and "oneshot::channel()" in text and "RecordHandler::initiate(" in text, fname
+        assert "// ..." not in text and "same `use` list" not in text, fname      # no elided parts
+    assert "impl MessageConsumer for GpuTaskConsumer" in open(os.path.join(ROOT, "rust", "gpu_filter_task.rs")).read()
+
+
 def test_library_loads_and_exports_every_declared_symbol():
     L = _lib.lib()
     for name in _declared_symbols():
