@@ -270,6 +270,74 @@ def main():
         ctx.set_option("trim_pool", 1)
         torch.cuda.empty_cache()
 
+    def run_ref_group_case(name, nb, rows_per_batch, where, seed=5, note=""):
+        """the reference's own schema (id:Int32, value1:Utf8(8), value2:Float32) in its own batch size, resident in HBM:
+        ONE group call (device-side join + the single-batch kernels) against the per-batch loop and the one-batch time"""
+        if args.only and args.only not in name:
+            return
+        nb = max(8, int(nb * args.scale))
+        n = nb * rows_per_batch
+        L8 = 8
+        g = torch.Generator(device=dev); g.manual_seed(seed)
+        ids = torch.arange(n, dtype=torch.int32, device=dev)
+        chars = torch.randint(ord("a"), ord("z") + 1, (n * L8,), dtype=torch.uint8, device=dev, generator=g)
+        offs = (torch.arange(rows_per_batch + 1, dtype=torch.int64, device=dev) * L8).to(torch.int32)   # batch-local offsets
+        v2 = torch.empty(n, dtype=torch.float32, device=dev).uniform_(0, 100, generator=g)
+        torch.cuda.synchronize()
+        al = [[], [], []]
+        pred = parse_expr(where)
+        devs = [chq.DeviceRecordBatch.from_device_pointers(
+            [("id", "i", ids.data_ptr() + 4 * b * rows_per_batch), ("value1", "u", offs.data_ptr(), chars.data_ptr() + L8 * b * rows_per_batch),
+             ("value2", "f", v2.data_ptr() + 4 * b * rows_per_batch)], rows_per_batch, ctx=ctx) for b in range(nb)]
+        grp = chq.RecordGroup(devs, ctx)
+        # parity: a few batches against the oracle
+        got = chq.filter_records(devs[:4], al, pred, ctx=ctx)
+        for b in range(4):
+            lo = b * rows_per_batch
+            host = pa.RecordBatch.from_arrays([
+                pa.array(ids[lo:lo + rows_per_batch].cpu().numpy()),
+                pa.Array.from_buffers(pa.utf8(), rows_per_batch, [None, pa.py_buffer(offs.cpu().numpy().tobytes()),
+                                                                  pa.py_buffer(chars[L8 * lo:L8 * (lo + rows_per_batch)].cpu().numpy().tobytes())]),
+                pa.array(v2[lo:lo + rows_per_batch].cpu().numpy())], names=["id", "value1", "value2"])
+            if not batches_identical(got[b].to_host(), O.filter_record(host, al, pred), check_nullable=False):
+                raise SystemExit(f"{name}: batch {b} differs from the oracle")
+        del got
+        per_call, coal = [], []
+        counts = None
+        for it in range(args.steps + 1):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            counts = chq.filter_records(grp, al, pred, ctx=ctx, wrap=False)
+            t1 = time.perf_counter()
+            if it: per_call.append((t1 - t0) * 1e3)
+        coalesced_ms = None
+        if n * L8 <= (1 << 30):
+            for it in range(args.steps + 1):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                big, rows_per = chq.filter_records_coalesced(grp, al, pred, ctx=ctx)
+                t1 = time.perf_counter()
+                assert rows_per == counts
+                big.release()
+                if it: coal.append((t1 - t0) * 1e3)
+            coalesced_ms = sorted(coal)[len(coal) // 2]
+        sub = min(nb, 500)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for b in range(sub):
+            chq.filter_record(devs[b], al, pred, ctx=ctx).release()
+        loop_us = (time.perf_counter() - t0) / sub * 1e6
+        rows_out = sum(counts)
+        alg = n * (4 + 4 + L8 + 4) + rows_out * (4 + 4 + L8 + 4)
+        per_call.sort()
+        r = {"case": name, "rows": n, "batches": nb, "rows_per_batch": rows_per_batch, "where": where, "rows_out": rows_out,
+             "group_call_ms": per_call[len(per_call) // 2], "coalesced_call_ms": coalesced_ms, "per_batch_loop_us_per_batch": loop_us,
+             "us_per_batch_group_call": per_call[len(per_call) // 2] * 1e3 / nb, "alg_bytes": alg,
+             "group_call_GBps": alg / (per_call[len(per_call) // 2] * 1e-3) / 1e9, "note": note}
+        results.append(r)
+        print(json.dumps(r), flush=True)
+        grp.release()
+        del devs, ids, chars, v2
+        ctx.set_option("trim_pool", 1)
+        torch.cuda.empty_cache()
+
     f3 = [("value0", "f32", 0, 100), ("value1", "f32", 0, 100), ("value2", "f32", 0, 100)]
     run_group_case("group2 value2>10, 10k-row batches", 1_000_000_000, 10_000, f3, "value2 > 10.0", seed=0xC0FFEE,
                    note="call wall time includes building the tile table, exporting and releasing every output batch through ctypes")
@@ -294,6 +362,10 @@ def main():
     run_case("config5-shape id%2=0, one record batch", 250_000_000, c5, "id % 2 = 0", seed=5,
              note="huge_simple.sql shape; one Utf8 array holds < 2 GiB of bytes (int32 offsets), so a 1.25 B-row GPU shard is "
                   "five such batches")
+    run_ref_group_case("refgroup id%2=0, 12 500 x 10k-row batches (1 GB of strings)", 12_500, 10_000, "id % 2 = 0",
+                       note="reference schema id:Int32, value1:Utf8(8), value2:Float32; per-batch outputs and the joined output")
+    run_ref_group_case("refgroup id%2=0, 100 000 x 10k-row batches", 100_000, 10_000, "id % 2 = 0",
+                       note="1 B rows = 8 GB of string bytes: eight joined chunks (int32 offsets), per-batch outputs only")
     if args.out:
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
         json.dump(results, open(args.out, "w"), indent=1)

@@ -1,6 +1,9 @@
 // capi.cpp -- the extern "C" surface declared in include/chq.h.
+#include <algorithm>
 #include <cstring>
+#include <exception>
 #include <new>
+#include <thread>
 
 #include "engine.hpp"
 
@@ -41,6 +44,24 @@ void finish(Context& c, Batch&& result_dev, int out_device, ArrowDeviceArray* ou
 }
 
 void require(const void* p, const char* what) { if (!p) throw ChqError{CHQ_ERR_INVALID_HANDLE, std::string("null ") + what}; }
+
+// f(i) for i in [0, n) on a few host threads when the group is large: importing / exporting 10^5 Arrow structs one after
+// the other (~0.3 + 0.4 us each) used to be 93 % of a group call (round 1).  The first error, if any, is rethrown.
+template <class F>
+void for_each_parallel(int n, F&& f) {
+  unsigned T = n < 4096 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (T <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::vector<std::thread> ts;
+  std::vector<std::exception_ptr> errs(T);
+  const int per = (n + (int)T - 1) / (int)T;
+  for (unsigned t = 0; t < T; ++t)
+    ts.emplace_back([&, t] {
+      try { for (int i = (int)t * per; i < std::min(n, (int)(t + 1) * per); ++i) f(i); }
+      catch (...) { errs[t] = std::current_exception(); }
+    });
+  for (auto& th : ts) th.join();
+  for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
 
 }  // namespace
 
@@ -210,15 +231,14 @@ chq_status chq_filter_records(chq_ctx* ctx, int n_records, const ArrowDeviceArra
     if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
       throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
     check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
-    std::vector<Batch> in;
-    in.reserve((size_t)n_records);
-    for (int i = 0; i < n_records; ++i) { require(recs[i], "record"); in.push_back(import_batch(recs[i], schema)); }
+    std::vector<Batch> in((size_t)n_records);
+    for (int i = 0; i < n_records; ++i) require(recs[i], "record");
+    for_each_parallel(n_records, [&](int i) { in[(size_t)i] = import_batch(recs[i], schema); });
     std::vector<Batch> res = filter_records(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM);
-    int done = 0;
     try {
-      for (; done < n_records; ++done) export_batch(std::move(res[(size_t)done]), out_device, &outs[done], &out_schemas[done]);
+      for_each_parallel(n_records, [&](int i) { export_batch(std::move(res[(size_t)i]), out_device, &outs[i], &out_schemas[i]); });
     } catch (...) {   // no partial output
-      for (int i = 0; i < done; ++i) {
+      for (int i = 0; i < n_records; ++i) {
         if (outs[i].array.release) outs[i].array.release(&outs[i].array);
         if (out_schemas[i].release) out_schemas[i].release(&out_schemas[i]);
       }
@@ -239,9 +259,9 @@ chq_status chq_filter_records_coalesced(chq_ctx* ctx, int n_records, const Arrow
     if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
       throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
     check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
-    std::vector<Batch> in;
-    in.reserve((size_t)n_records);
-    for (int i = 0; i < n_records; ++i) { require(recs[i], "record"); in.push_back(import_batch(recs[i], schema)); }
+    std::vector<Batch> in((size_t)n_records);
+    for (int i = 0; i < n_records; ++i) require(recs[i], "record");
+    for_each_parallel(n_records, [&](int i) { in[(size_t)i] = import_batch(recs[i], schema); });
     std::vector<int64_t> rows;
     Batch res = filter_records_coalesced(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &rows);
     if (rows_per_record) for (int i = 0; i < n_records; ++i) rows_per_record[i] = rows[(size_t)i];

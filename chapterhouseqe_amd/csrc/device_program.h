@@ -231,6 +231,24 @@ struct GatherParams {      // gather_i32_kernel: dst[i] = *src[i]  (batches tiny
   int32_t pad;
 };
 
+// concat_*_kernel: the batches of a device-resident group joined into one batch (engine.cpp: concat_device_batches).
+// Per-batch tables of nb entries: `src` = buffer address (fixed width: values at row 0; Utf8: int32 offsets at row 0;
+// bitmaps: the bitmap, 0 = "all ones"), `aux` = Utf8 data buffer, `bitoff` = first bit of a bitmap; row_at / byte_at are
+// exclusive prefix sums (nb + 1 entries) of the batches' rows / Utf8 bytes.
+struct ConcatParams {
+  int64_t nb;
+  const u64* src;
+  const u64* aux;
+  const int64_t* bitoff;
+  const int64_t* row_at;
+  const int64_t* byte_at;
+  void* dst;           // values / offsets / bitmap (zero-initialised for bitmaps)
+  void* dst2;          // Utf8 data
+  int32_t* ends;       // gather_ends_kernel: first and last offset of every batch (2 nb entries)
+  int32_t width;
+  int32_t pad;
+};
+
 struct Utf8Params {
   int64_t nrows;
   const u64* sel_mask;

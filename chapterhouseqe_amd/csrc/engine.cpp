@@ -1248,6 +1248,135 @@ void ensure_pinned_table(Context& ctx, size_t bytes) {
   check_hip(hipHostMalloc(&ctx.pinned_tbl, cap, hipHostMallocDefault), "hipHostMalloc (group table)");
   ctx.pinned_tbl_bytes = cap;
 }
+
+// ---- device-side concatenation of a group (general column kinds) ----------------------------------------------------
+// The batches of recs[b0, b1) -- all resident in this GPU's HBM, one schema -- joined into ONE batch by the concat_*
+// kernels: fixed-width values copied back to back, Utf8 offsets rebased onto one data buffer, Boolean values and validity
+// bitmaps appended bit by bit.  `utf8_bytes[k][b]` = data bytes of the k-th Utf8 column of batch b (from gather_ends).
+Batch concat_device_batches(Context& ctx, const std::vector<Batch>& recs, size_t b0, size_t b1,
+                            const std::vector<int>& utf8_cols, const std::vector<std::vector<int64_t>>& utf8_bytes) {
+  const size_t nb = b1 - b0, nc = recs[b0].cols.size();
+  Batch cat;
+  cat.on_device = true; cat.device_id = ctx.device;
+  // ---- tables: [row_at (nb+1)] then per column [src nb] [aux nb | -] [bitoff nb | -] [byte_at nb+1 | -] [vsrc nb, vbitoff nb | -]
+  struct ColPlan { size_t src = 0, aux = 0, bitoff = 0, byte_at = 0, vsrc = 0, vbitoff = 0; bool validity = false; int utf8_k = -1; };
+  std::vector<ColPlan> plan(nc);
+  size_t words = nb + 1;
+  for (size_t c = 0; c < nc; ++c) {
+    const Column& c0 = recs[b0].cols[c];
+    plan[c].src = words; words += nb;
+    if (c0.type == T_UTF8) {
+      plan[c].aux = words; words += nb;
+      plan[c].byte_at = words; words += nb + 1;
+      plan[c].utf8_k = (int)(std::find(utf8_cols.begin(), utf8_cols.end(), (int)c) - utf8_cols.begin());
+    }
+    if (c0.type == T_BOOL) { plan[c].bitoff = words; words += nb; }
+    for (size_t b = b0; b < b1 && !plan[c].validity; ++b) plan[c].validity = recs[b].cols[c].validity && recs[b].cols[c].null_count != 0;
+    if (plan[c].validity) { plan[c].vsrc = words; words += nb; plan[c].vbitoff = words; words += nb; }
+  }
+  ensure_pinned_table(ctx, words * 8);
+  u64* h = (u64*)ctx.pinned_tbl;
+  int64_t total = 0;
+  for (size_t k = 0; k < nb; ++k) { h[k] = (u64)total; total += recs[b0 + k].nrows; }
+  h[nb] = (u64)total;
+  cat.nrows = total;
+  std::vector<int64_t> total_bytes(nc, 0);
+  std::vector<int64_t> known_nulls(nc, 0);
+  for (size_t c = 0; c < nc; ++c) {
+    const ColPlan& pl = plan[c];
+    int64_t bytes = 0;
+    for (size_t k = 0; k < nb; ++k) {
+      const Column& col = recs[b0 + k].cols[c];
+      h[pl.src + k] = (u64)(uintptr_t)(col.type == T_BOOL ? (const void*)col.values : col.values0());
+      if (col.type == T_UTF8) {
+        h[pl.aux + k] = (u64)(uintptr_t)col.data;
+        h[pl.byte_at + k] = (u64)bytes;
+        bytes += utf8_bytes[(size_t)pl.utf8_k][b0 + k];
+      }
+      if (col.type == T_BOOL) h[pl.bitoff + k] = (u64)col.offset;
+      if (pl.validity) {
+        const bool has = col.validity && col.null_count != 0;
+        h[pl.vsrc + k] = has ? (u64)(uintptr_t)col.validity : 0;
+        h[pl.vbitoff + k] = (u64)col.offset;
+        if (has && col.null_count > 0) known_nulls[c] += col.null_count;
+      }
+    }
+    if (recs[b0].cols[c].type == T_UTF8) { h[pl.byte_at + nb] = (u64)bytes; total_bytes[c] = bytes; }
+  }
+  auto d_tbl = make_device_buffer(words * 8 + 16, ctx.device);
+  check_hip(hipMemcpyAsync(d_tbl->ptr, h, words * 8, hipMemcpyHostToDevice, ctx.stream), "upload concat tables");
+  const u64* d = (const u64*)d_tbl->ptr;
+  const int grid = (int)std::min<int64_t>((int64_t)nb, (int64_t)ctx.num_cus * 16);
+  for (size_t c = 0; c < nc; ++c) {
+    const Column& c0 = recs[b0].cols[c];
+    const ColPlan& pl = plan[c];
+    Column o = empty_like(c0);
+    o.length = total;
+    ConcatParams cp{};
+    cp.nb = (int64_t)nb; cp.row_at = (const int64_t*)d; cp.src = d + pl.src;
+    if (pl.validity) {
+      const size_t vbytes = (size_t)(total + 31) / 32 * 4 + 16;
+      auto vb = make_device_buffer(vbytes, ctx.device);
+      check_hip(hipMemsetAsync(vb->ptr, 0, vbytes, ctx.stream), "memset validity");
+      ConcatParams vp = cp;
+      vp.src = d + pl.vsrc; vp.bitoff = (const int64_t*)(d + pl.vbitoff); vp.dst = vb->ptr;
+      check_hip(launch_concat(vp, 3, grid, ctx.stream), "launch concat_bits_kernel (validity)");
+      o.validity = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+      o.null_count = known_nulls[c] > 0 ? known_nulls[c] : 1;   // "may contain nulls": the filter counts what survives
+    }
+    if (c0.type == T_BOOL) {
+      const size_t bbytes = (size_t)(total + 31) / 32 * 4 + 16;
+      auto vb = make_device_buffer(bbytes, ctx.device);
+      check_hip(hipMemsetAsync(vb->ptr, 0, bbytes, ctx.stream), "memset bits");
+      cp.bitoff = (const int64_t*)(d + pl.bitoff); cp.dst = vb->ptr;
+      check_hip(launch_concat(cp, 3, grid, ctx.stream), "launch concat_bits_kernel");
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    } else if (c0.type == T_UTF8) {
+      auto ob = make_device_buffer((size_t)(total + 1) * 4 + 16, ctx.device);
+      auto db = make_device_buffer((size_t)total_bytes[c] + 16, ctx.device);
+      cp.aux = d + pl.aux; cp.byte_at = (const int64_t*)(d + pl.byte_at); cp.dst = ob->ptr; cp.dst2 = db->ptr;
+      if (total == 0) check_hip(hipMemsetAsync(ob->ptr, 0, 4, ctx.stream), "memset offsets");
+      check_hip(launch_concat(cp, 2, grid, ctx.stream), "launch concat_utf8_kernel");
+      o.values = (const uint8_t*)ob->ptr; o.owned.push_back(ob);
+      o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
+    } else {
+      auto vb = make_device_buffer((size_t)total * c0.width + 16, ctx.device);
+      cp.dst = vb->ptr; cp.width = c0.width;
+      check_hip(launch_concat(cp, 0, grid, ctx.stream), "launch concat_fixed_kernel");
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    }
+    cat.cols.push_back(std::move(o));
+  }
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the pinned table is reused by the next chunk
+  return cat;
+}
+
+// data bytes of every Utf8 column of every batch of a device-resident group (first / last offset read by one kernel)
+std::vector<std::vector<int64_t>> device_utf8_bytes(Context& ctx, const std::vector<Batch>& recs, const std::vector<int>& utf8_cols) {
+  const size_t nb = recs.size();
+  std::vector<std::vector<int64_t>> out(utf8_cols.size(), std::vector<int64_t>(nb, 0));
+  if (utf8_cols.empty()) return out;
+  const size_t words = (nb + 1) + nb;
+  ensure_pinned_table(ctx, words * 8 + nb * 8);
+  u64* h = (u64*)ctx.pinned_tbl;
+  int64_t total = 0;
+  for (size_t b = 0; b < nb; ++b) { h[b] = (u64)total; total += recs[b].nrows; }
+  h[nb] = (u64)total;
+  auto d_tbl = make_device_buffer(words * 8 + nb * 8 + 16, ctx.device);
+  int32_t* d_ends = (int32_t*)((u64*)d_tbl->ptr + words);
+  int32_t* h_ends = (int32_t*)(h + words);
+  for (size_t k = 0; k < utf8_cols.size(); ++k) {
+    for (size_t b = 0; b < nb; ++b) h[nb + 1 + b] = (u64)(uintptr_t)recs[b].cols[utf8_cols[k]].values0();
+    check_hip(hipMemcpyAsync(d_tbl->ptr, h, words * 8, hipMemcpyHostToDevice, ctx.stream), "upload offsets table");
+    ConcatParams cp{};
+    cp.nb = (int64_t)nb; cp.row_at = (const int64_t*)d_tbl->ptr; cp.src = (const u64*)d_tbl->ptr + nb + 1; cp.ends = d_ends;
+    check_hip(launch_concat(cp, 1, 1, ctx.stream), "launch gather_ends_kernel");
+    check_hip(hipMemcpyAsync(h_ends, d_ends, nb * 8, hipMemcpyDeviceToHost, ctx.stream), "read back ends");
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+    for (size_t b = 0; b < nb; ++b) out[k][b] = (int64_t)h_ends[2 * b + 1] - h_ends[2 * b];
+  }
+  return out;
+}
 }  // namespace
 
 namespace {
@@ -1356,6 +1485,69 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     return outs;
   };
 
+  // ---- device-resident batches with Utf8 / Boolean / nullable columns (the reference's own schema is Int32, Utf8,
+  // Float32: create_sample_data.rs:157-204): joined on the device by the concat kernels, filtered as ONE batch by the
+  // ordinary kernels, cut at the batch boundaries the device reports (split_bounds_kernel).  Every output batch is a
+  // slice (Arrow offset) of the shared result buffers; chunks keep every Utf8 column below the int32 offset range.
+  auto device_concat_path = [&]() -> std::vector<Batch> {
+    const size_t nc = recs[0].cols.size();
+    std::vector<int> utf8_cols;
+    for (size_t i = 0; i < nc; ++i) if (recs[0].cols[i].type == T_UTF8) utf8_cols.push_back((int)i);
+    const std::vector<std::vector<int64_t>> ubytes = device_utf8_bytes(ctx, recs, utf8_cols);
+    std::vector<size_t> cuts{0};
+    {
+      std::vector<int64_t> bytes(utf8_cols.size(), 0);
+      int64_t rows = 0;
+      for (size_t b = 0; b < nb; ++b) {
+        bool over = rows + recs[b].nrows > (1ll << 30);
+        for (size_t k = 0; k < utf8_cols.size(); ++k) over |= bytes[k] + ubytes[k][b] > ctx.opt_group_chunk_bytes;
+        if (over && b > cuts.back()) { cuts.push_back(b); std::fill(bytes.begin(), bytes.end(), 0); rows = 0; }
+        for (size_t k = 0; k < utf8_cols.size(); ++k) bytes[k] += ubytes[k][b];
+        rows += recs[b].nrows;
+      }
+      cuts.push_back(nb);
+    }
+    if (co && cuts.size() > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "offset overflow: the joined Utf8 output of this group does not fit int32 offsets; use chq_filter_records"};
+    std::vector<Batch> outs;
+    if (!co) outs.reserve(nb);
+    chq_call_stats acc{};
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+      const size_t b0 = cuts[k], b1 = cuts[k + 1];
+      Batch cat = concat_device_batches(ctx, recs, b0, b1, utf8_cols, ubytes);
+      SplitRequest split;
+      int64_t at = 0;
+      for (size_t b = b0; b < b1; ++b) { split.starts.push_back(at); at += recs[b].nrows; }
+      split.starts.push_back(at);
+      Batch res = filter_record(ctx, cat, plan_columns(cat, aliases), expr, &split);
+      add_stats(acc, ctx.stats);
+      if (co) {
+        for (size_t b = b0; b < b1; ++b) co->rows.push_back(split.bounds[b - b0 + 1] - split.bounds[b - b0]);
+        co->out = out_on_device ? std::move(res) : to_host(ctx, res);
+        co->done = true;
+        continue;
+      }
+      Batch whole = out_on_device ? std::move(res) : to_host(ctx, res);
+      for (size_t b = b0; b < b1; ++b) {
+        const int64_t begin = split.bounds[b - b0], end = split.bounds[b - b0 + 1];
+        Batch o;
+        o.on_device = out_on_device; o.device_id = out_on_device ? ctx.device : -1; o.nrows = end - begin;
+        o.cols.reserve(whole.cols.size());
+        for (const Column& c : whole.cols) {
+          Column sc = c;   // shares the result buffers
+          sc.offset = c.offset + begin; sc.length = end - begin;
+          if (sc.validity) {
+            if (out_on_device) sc.null_count = -1;   // unknown for the slice (Arrow C Data Interface: -1)
+            else { sc.null_count = count_nulls_host(sc.validity, sc.offset, sc.length); if (sc.null_count == 0) sc.validity = nullptr; }
+          } else sc.null_count = 0;
+          o.cols.push_back(std::move(sc));
+        }
+        outs.push_back(std::move(o));
+      }
+    }
+    ctx.stats = acc;
+    return outs;
+  };
+
   // ---- eligibility -----------------------------------------------------------------------------------
   const size_t ncols = recs[0].cols.size();
   if (ncols == 0) return per_batch_loop();
@@ -1372,7 +1564,10 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   }
   if (!same_schema) return per_batch_loop();
   if (!plain) {
-    if (!all_host || out_on_device) return per_batch_loop();
+    bool all_device = true;
+    for (const Batch& r : recs) all_device &= r.on_device && r.device_id == ctx.device;
+    const bool host_case = all_host && !out_on_device;
+    if (!host_case && !all_device) return per_batch_loop();
     try {
       TypedExpr probe = type_expr(expr, plan_columns(recs[0], aliases), recs[0].nrows, ctx.opt_enable_minus);
       if (probe.pending_code || probe.at(probe.root).type != T_BOOL || probe.at(probe.root).len1) return per_batch_loop();
@@ -1380,8 +1575,9 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
       return per_batch_loop();   // reports the first batch's (static) error
     }
     try {
-      return host_concat_path();
-    } catch (const ChqError&) {
+      return host_case ? host_concat_path() : device_concat_path();
+    } catch (const ChqError& e) {
+      if (e.code == CHQ_ERR_OUT_OF_MEMORY || e.code == CHQ_ERR_DEVICE) throw;
       return per_batch_loop();   // a data-dependent error: the loop reports the earliest failing batch's
     }
   }

@@ -26,6 +26,7 @@ hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream)
 hipError_t launch_split_bounds(const SplitBoundsParams& p, hipStream_t stream);
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream);
+hipError_t launch_concat(const ConcatParams& p, int kind, int grid, hipStream_t stream);   // kind: 0 fixed, 1 ends, 2 utf8, 3 bits
 
 // ---- memory ---------------------------------------------------------------------------------------
 // Process-wide caching allocator for HBM (outlives contexts: Arrow release callbacks may run after the

@@ -1825,6 +1825,97 @@ hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(gather_i32_kernel, dim3(1), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
+// ------------------------------------------------------------------------------------------------
+// Joining the batches of a device-resident group into one batch (filter_task.rs:78-126 hoisted below the boundary for
+// groups with Utf8 / Boolean / nullable columns: the joined batch goes through the ordinary single-batch kernels, the
+// outputs are cut at the batch boundaries afterwards).  One workgroup per batch, grid-stride.
+// ------------------------------------------------------------------------------------------------
+template <typename TY>
+__global__ __launch_bounds__(256) void concat_fixed_kernel(const ConcatParams p) {
+  for (int64_t b = blockIdx.x; b < p.nb; b += gridDim.x) {
+    const int64_t r0 = p.row_at[b], n = p.row_at[b + 1] - r0;
+    const TY* src = (const TY*)p.src[b];
+    TY* dst = (TY*)p.dst + r0;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < n; i += 1024) {   // four loads in flight per thread
+      const TY a = src[i], bq = src[i + 256], c = src[i + 512], d = src[i + 768];
+      dst[i] = a; dst[i + 256] = bq; dst[i + 512] = c; dst[i + 768] = d;
+    }
+    for (; i < n; i += 256) dst[i] = src[i];
+  }
+}
+__global__ __launch_bounds__(256) void gather_ends_kernel(const ConcatParams p) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.nb) return;
+  const int32_t* offs = (const int32_t*)p.src[b];
+  const int64_t n = p.row_at[b + 1] - p.row_at[b];
+  p.ends[2 * b] = offs ? offs[0] : 0;
+  p.ends[2 * b + 1] = offs ? offs[n] : 0;
+}
+__global__ __launch_bounds__(256) void concat_utf8_kernel(const ConcatParams p) {
+  for (int64_t b = blockIdx.x; b < p.nb; b += gridDim.x) {
+    const int64_t r0 = p.row_at[b], n = p.row_at[b + 1] - r0;
+    const int64_t y0 = p.byte_at[b], nbytes = p.byte_at[b + 1] - y0;
+    const int32_t* soff = (const int32_t*)p.src[b];
+    int32_t* doff = (int32_t*)p.dst + r0;
+    const int32_t first = (soff && n > 0) ? soff[0] : 0;
+    const int32_t shift = (int32_t)(y0 - first);
+    for (int64_t i = threadIdx.x; i < n; i += 256) doff[i] = soff[i] + shift;
+    if (b == p.nb - 1 && threadIdx.x == 0) doff[n] = (int32_t)(y0 + nbytes);   // the closing offset of the joined column
+    const uint8_t* sd = (const uint8_t*)p.aux[b] + first;
+    uint8_t* dd = (uint8_t*)p.dst2 + y0;
+    const int64_t words = nbytes >> 2;
+    for (int64_t i = threadIdx.x; i < words; i += 256) { uint32_t w; __builtin_memcpy(&w, sd + 4 * i, 4); __builtin_memcpy(dd + 4 * i, &w, 4); }
+    if (threadIdx.x < (nbytes & 3)) dd[4 * words + threadIdx.x] = sd[4 * words + threadIdx.x];
+  }
+}
+// bits [bitoff[b], bitoff[b] + n_b) of every batch's bitmap appended at bit row_at[b] of the zero-initialised output; a batch
+// without a bitmap (src 0) contributes ones.  32 bits per thread, merged with atomicOr (neighbouring batches share words).
+__global__ __launch_bounds__(256) void concat_bits_kernel(const ConcatParams p) {
+  for (int64_t b = blockIdx.x; b < p.nb; b += gridDim.x) {
+    const int64_t r0 = p.row_at[b], n = p.row_at[b + 1] - r0;
+    const uint8_t* src = (const uint8_t*)p.src[b];
+    const int64_t so = p.bitoff[b];
+    for (int64_t k = threadIdx.x; 32 * k < n; k += 256) {
+      const int cnt = (int)(n - 32 * k < 32 ? n - 32 * k : 32);
+      uint32_t v = 0xffffffffu;
+      if (src) {
+        const int64_t sb = so + 32 * k;               // first source bit
+        const uint8_t* q = src + (sb >> 3);
+        const int sh = (int)(sb & 7);
+        const int need = (sh + cnt + 7) >> 3;          // 1..5 bytes hold the bits
+        u64 raw = 0;
+        for (int t = 0; t < need; ++t) raw |= (u64)q[t] << (8 * t);
+        v = (uint32_t)(raw >> sh);
+      }
+      if (cnt < 32) v &= (1u << cnt) - 1u;
+      const int64_t d = r0 + 32 * k;
+      uint32_t* dw = (uint32_t*)p.dst + (d >> 5);
+      const int ds = (int)(d & 31);
+      if (v << ds) atomicOr(dw, v << ds);
+      if (ds && (v >> (32 - ds))) atomicOr(dw + 1, v >> (32 - ds));
+    }
+  }
+}
+hipError_t launch_concat(const ConcatParams& p, int kind, int grid, hipStream_t stream) {   // kind: 0 fixed, 1 ends, 2 utf8, 3 bits
+  if (p.nb <= 0) return hipSuccess;
+  switch (kind) {
+    case 0:
+      switch (p.width) {
+        case 1: hipLaunchKernelGGL((concat_fixed_kernel<uint8_t>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL((concat_fixed_kernel<uint16_t>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((concat_fixed_kernel<uint32_t>), dim3(grid), dim3(256), 0, stream, p); break;
+        case 8: hipLaunchKernelGGL((concat_fixed_kernel<uint2>), dim3(grid), dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL((concat_fixed_kernel<uint4>), dim3(grid), dim3(256), 0, stream, p); break;
+      }
+      break;
+    case 1: hipLaunchKernelGGL(gather_ends_kernel, dim3((unsigned)((p.nb + 255) / 256)), dim3(256), 0, stream, p); break;
+    case 2: hipLaunchKernelGGL(concat_utf8_kernel, dim3(grid), dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL(concat_bits_kernel, dim3(grid), dim3(256), 0, stream, p); break;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream) {   // 8192-row tiles
   hipLaunchKernelGGL((utf8_filter_kernel<1024, 8>), dim3(grid), dim3(1024), 0, stream, p);
   return hipGetLastError();

@@ -131,8 +131,8 @@ def mixed_batch(n, seed, nulls):
 
 @pytest.mark.parametrize("device", [True, False], ids=["device", "host"])
 def test_groups_outside_the_one_launch_path(ctx, device):
-    """Utf8 / Boolean / nullable columns, 0- and 1-row batches, literal-only predicates: same results.  Device-resident
-    groups run batch by batch inside the call; host groups are concatenated while staging (next test)."""
+    """Utf8 / Boolean / nullable columns, 0- and 1-row batches, literal-only predicates: same results.  Such groups are
+    joined -- on the host while staging, on the GPU when they live in HBM (next tests) -- or run batch by batch."""
     groups = [
         ([mixed_batch(n, 40 + n, False) for n in (100, 3000, 17)], "a > 50 and s <> 'ab'"),
         ([mixed_batch(n, 50 + n, True) for n in (100, 3000, 17)], "a > 50 or f"),
@@ -166,6 +166,69 @@ def test_host_groups_with_strings_booleans_and_nulls_are_concatenated(chunk_byte
         chq.filter_records(bad, empty_aliases(bad[0]), parse_expr("a + 1 > 0"), ctx=c)
     assert ei.value.code == 20
     c.close()
+
+
+@pytest.mark.parametrize("chunk_bytes", [1 << 30, 20_000], ids=["one-chunk", "many-chunks"])
+def test_device_groups_with_strings_booleans_and_nulls_are_joined_on_the_gpu(chunk_bytes):
+    """the same group resident in HBM (what a GPU scan / a previous GPU operator hands over): joined by the concat kernels,
+    filtered as ONE batch, cut per record id -- a handful of launches, not 150 x (main + follow-up kernels)"""
+    c = chq.Context(0)
+    c.set_option("group_chunk_bytes", chunk_bytes)
+    sizes = [int(x) for x in np.random.default_rng(2).integers(2, 900, 150)]
+    recs = []
+    for i, n in enumerate(sizes):
+        b = mixed_batch(n + 11, 3000 + i, nulls=(i % 3 != 0))
+        recs.append(b.slice(5 + i % 7, n) if i % 2 else b.slice(0, n))
+    al = empty_aliases(recs[0])
+    devs = [chq.DeviceRecordBatch.from_host(r, c) for r in recs]
+    for sql in ["a > 50 and s <> 'ab'", "f or d * 2.0 > 15.0", "s >= 'ab'", "a % 7 = 0", "a = a", "d < 0.0"]:
+        e = parse_expr(sql)
+        exp = [O.filter_record(r, al, e) for r in recs]
+        for out_host in (False, True):
+            got = chq.filter_records(devs, al, e, ctx=c, device_result=not out_host)
+            st = c.last_stats()
+            assert len(got) == len(exp)
+            for i, (g, x) in enumerate(zip(got, exp)):
+                g = g.to_host() if hasattr(g, "to_host") else g
+                assert batches_identical(g, x), f"{sql}: batch {i} ({recs[i].num_rows} rows):\n{explain_diff(g, x)}"
+            if chunk_bytes == 1 << 30:
+                assert st["launches"] <= 12, (sql, st)
+    if chunk_bytes == 1 << 30:   # the joined form: one output batch + rows per input batch
+        e = parse_expr("a > 50 or f")
+        parts = [O.filter_record(r, al, e) for r in recs]
+        whole = pa.Table.from_batches(parts).combine_chunks().to_batches()[0]
+        got, rows = chq.filter_records_coalesced(devs, al, e, ctx=c)
+        assert rows == [p.num_rows for p in parts]
+        assert batches_identical(got.to_host(), whole, check_nullable=False), explain_diff(got.to_host(), whole)
+    bad = list(recs)
+    bad[77] = pa.RecordBatch.from_arrays([pa.array(np.full(20, 2**31 - 1, dtype=np.int32)), pa.array(["x"] * 20, type=pa.utf8()),
+                                          pa.array([True] * 20), pa.array(np.zeros(20))], names=["a", "s", "f", "d"])
+    bad_dev = [chq.DeviceRecordBatch.from_host(r, c) for r in bad]
+    with pytest.raises(chq.ChqError) as ei:
+        chq.filter_records(bad_dev, al, parse_expr("a + 1 > 0"), ctx=c)
+    assert ei.value.code == 20
+    c.close()
+
+
+def test_reference_schema_group_resident_in_hbm(ctx):
+    """the reference's own schema (id:Int32, value1:Utf8(8), value2:Float32, create_sample_data.rs:157-204) in its own batch
+    size (10 000 rows, physical_planner.rs:323), 300 batches resident in HBM, the sample queries' predicates"""
+    from chapterhouseqe_amd.sample_data import simple_batches
+    recs = simple_batches(3_000_000, 8, 10_000)
+    al = empty_aliases(recs[0])
+    devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]
+    for sql in ["id % 2 = 0", "value2 > 10.0", "value1 >= 'n' and id > 25"]:
+        e = parse_expr(sql)
+        got = chq.filter_records(devs, al, e, ctx=ctx)
+        assert ctx.last_stats()["launches"] <= 8
+        for i in (0, 1, 150, 299):
+            assert batches_identical(got[i].to_host(), O.filter_record(recs[i], al, e)), (sql, i)
+        rows = [g.num_rows for g in got]
+        big, per = chq.filter_records_coalesced(devs, al, e, ctx=ctx)
+        assert per == rows and big.num_rows == sum(rows)
+        exp0 = O.filter_record(recs[0], al, e)
+        head = big.to_host().slice(0, exp0.num_rows)
+        assert batches_identical(head, exp0, check_nullable=False), sql
 
 
 def test_a_single_null_leaves_the_one_launch_path(ctx):
