@@ -60,6 +60,15 @@ class ColumnDesc(C.Structure):
                 ("offset", C.c_int64), ("validity", C.c_void_p), ("values", C.c_void_p), ("data", C.c_void_p)]
 
 
+class IpcMessage(C.Structure):
+    pass
+
+
+IpcMessage._fields_ = [("header", C.c_void_p), ("header_len", C.c_int64), ("body", C.c_void_p), ("body_len", C.c_int64),
+                       ("body_device_type", C.c_int32), ("body_device_id", C.c_int32), ("end_of_stream", C.c_uint8 * 8),
+                       ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 class CallStats(C.Structure):
     _fields_ = [("rows_in", C.c_int64), ("rows_out", C.c_int64), ("tiles", C.c_int64), ("launches", C.c_int64),
                 ("bytes_read_alg", C.c_int64), ("bytes_written_alg", C.c_int64), ("kernel_ns", C.c_int64)]
@@ -72,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "chq_expr_boolean", "chq_expr_single_quoted_string", "chq_expr_unsupported_value", "chq_expr_binary_op",
     "chq_expr_nested", "chq_expr_unsupported", "chq_expr_free", "chq_filter_record", "chq_filter_records", "chq_filter_records_coalesced", "chq_plan_describe", "chq_project_record",
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
-    "chq_record_copy_to_peer",
+    "chq_record_copy_to_peer", "chq_record_to_ipc", "chq_record_from_ipc", "chq_ipc_describe",
 ]
 
 
@@ -142,6 +151,9 @@ def lib():
         "chq_record_to_device": (ci, [vp, PDA, PS, PDA, PS]), "chq_record_to_host": (ci, [vp, PDA, PS, PDA, PS]),
         "chq_wrap_columns": (ci, [vp, C.POINTER(ColumnDesc), ci, i64, ci, PDA, PS]),
         "chq_record_copy_to_peer": (ci, [vp, vp, PDA, PS, PDA, PS]),
+        "chq_record_to_ipc": (ci, [vp, PDA, PS, ci, C.POINTER(IpcMessage)]),
+        "chq_record_from_ipc": (ci, [vp, vp, i64, vp, i64, ci, ci, PDA, PS]),
+        "chq_ipc_describe": (ci, [vp, i64, C.c_char_p, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         try:

@@ -375,6 +375,71 @@ chq_status chq_record_copy_to_peer(chq_ctx* src_ctx, chq_ctx* dst_ctx, const Arr
   });
 }
 
+namespace {
+struct IpcHolder { IpcMessage msg; };
+void release_ipc(chq_ipc_message* m) {
+  if (!m || !m->release) return;
+  delete (IpcHolder*)m->private_data;
+  memset(m, 0, sizeof(*m));
+}
+}  // namespace
+
+chq_status chq_record_to_ipc(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, int body_device,
+                             chq_ipc_message* out) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  if (out) memset(out, 0, sizeof(*out));
+  return guarded(ctx, [&] {
+    require(out, "output message");
+    if (body_device != ARROW_DEVICE_ROCM && body_device != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "body_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    Batch dev = to_device(ctx->c, in);   // (a host batch is staged: the body is assembled by the device either way)
+    auto* h = new IpcHolder();
+    try {
+      h->msg = record_to_ipc(ctx->c, dev, body_device == ARROW_DEVICE_ROCM);
+    } catch (...) { delete h; throw; }
+    out->header = h->msg.header.data(); out->header_len = (int64_t)h->msg.header.size();
+    out->body = h->msg.body->ptr; out->body_len = h->msg.body_len;
+    out->body_device_type = h->msg.body_on_device ? ARROW_DEVICE_ROCM : ARROW_DEVICE_CPU;
+    out->body_device_id = h->msg.body_on_device ? ctx->c.device : -1;
+    const uint8_t eos[8] = {0xff, 0xff, 0xff, 0xff, 0, 0, 0, 0};
+    memcpy(out->end_of_stream, eos, 8);
+    out->release = release_ipc; out->private_data = h;
+  });
+}
+
+chq_status chq_record_from_ipc(chq_ctx* ctx, const uint8_t* stream, int64_t stream_len, const void* body, int64_t body_len,
+                               int body_device_type, int out_device, ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema"); require(stream, "stream");
+    if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    if (body && body_device_type != ARROW_DEVICE_ROCM && body_device_type != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "body_device_type must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch res = record_from_ipc(ctx->c, stream, stream_len, body, body_len, body_device_type == ARROW_DEVICE_ROCM,
+                                out_device == ARROW_DEVICE_ROCM);
+    export_batch(std::move(res), out_device, out, out_schema);
+  });
+}
+
+chq_status chq_ipc_describe(const uint8_t* stream, int64_t stream_len, char* buf, size_t buf_len) {
+  std::string text;
+  chq_status st = CHQ_OK;
+  try {
+    text = describe_ipc(stream, stream_len);
+  } catch (const ChqError& e) {
+    text = e.msg; st = (chq_status)e.code;
+  } catch (const std::exception& e) {
+    text = e.what(); st = CHQ_ERR_ARROW_INVALID_ARGUMENT;
+  }
+  if (buf && buf_len) { const size_t k = std::min(buf_len - 1, text.size()); memcpy(buf, text.data(), k); buf[k] = 0; }
+  return st;
+}
+
 chq_status chq_record_to_host(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, ArrowDeviceArray* out,
                               ArrowSchema* out_schema) {
   if (!ctx) return CHQ_ERR_INVALID_HANDLE;

@@ -133,7 +133,9 @@ const void* Column::values0() const {
   return values ? values + (int64_t)width * offset : nullptr;
 }
 
-static void parse_format(const char* f, DType* t, int* width) {
+void parse_arrow_format(const char* f, DType* t, int* width);
+static void parse_format(const char* f, DType* t, int* width) { parse_arrow_format(f, t, width); }
+void parse_arrow_format(const char* f, DType* t, int* width) {
   *width = 0;
   if (f && f[0] && !f[1]) {   // the primitive types are one character: no string object on the per-batch import path
     switch (f[0]) {

@@ -181,6 +181,23 @@ Column compute_value(Context& ctx, const Batch& rec_dev, const std::vector<PlanC
 
 std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* aliases);
 
+// Arrow C format string -> column kind and byte width (throws CHQ_ERR_NOT_SUPPORTED outside the build's scope)
+void parse_arrow_format(const char* format, DType* type, int* width);
+
+// ---- Arrow IPC stream with the body in HBM (ipc.cpp) ------------------------------------------------------------------
+struct IpcMessage {
+  std::vector<uint8_t> header;   // host: Schema message + the RecordBatch message's framing and metadata
+  BufferPtr body;                // every Arrow buffer, 64-byte aligned, back to back
+  int64_t body_len = 0;
+  bool body_on_device = true;
+  BufferPtr keep;
+};
+IpcMessage record_to_ipc(Context& ctx, const Batch& rec_dev, bool body_on_device);
+// `body` null: the body follows the batch message inside `stream` (a complete host stream)
+std::string describe_ipc(const uint8_t* stream, int64_t stream_len);   // host only
+Batch record_from_ipc(Context& ctx, const uint8_t* stream, int64_t stream_len, const void* body, int64_t body_len,
+                      bool body_on_device, bool out_on_device);
+
 // host-only: result type / flags and the lowered device program of `expr` over a schema (text); throws the static error
 std::string describe_plan(const ArrowSchema* schema, const chq_table_aliases* aliases, const Expr& expr, int64_t nrows,
                           bool enable_minus);

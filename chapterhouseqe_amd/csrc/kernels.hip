@@ -1916,6 +1916,59 @@ hipError_t launch_concat(const ConcatParams& p, int kind, int grid, hipStream_t 
   return hipGetLastError();
 }
 
+// ---- Arrow IPC body assembly (ipc.cpp): the pieces a plain device copy cannot place --------------------------------------
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(const int32_t* in, int32_t* out, int64_t n) {
+  const int32_t first = in[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i] - first;
+}
+// out word k = bits [bit_offset + 32 k, +32) of `in` (bits past `nbits` are zero): a sliced bitmap rebased to bit 0
+__global__ __launch_bounds__(256) void bit_shift_copy_kernel(const uint8_t* in, int64_t bit_offset, int64_t nbits, uint32_t* out) {
+  const int64_t words = (nbits + 31) >> 5;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (int64_t)gridDim.x * 256) {
+    const int cnt = (int)(nbits - 32 * k < 32 ? nbits - 32 * k : 32);
+    const int64_t sb = bit_offset + 32 * k;
+    const uint8_t* q = in + (sb >> 3);
+    const int sh = (int)(sb & 7);
+    const int need = (sh + cnt + 7) >> 3;
+    u64 raw = 0;
+    for (int t = 0; t < need; ++t) raw |= (u64)q[t] << (8 * t);
+    uint32_t v = (uint32_t)(raw >> sh);
+    if (cnt < 32) v &= (1u << cnt) - 1u;
+    out[k] = v;
+  }
+}
+__global__ __launch_bounds__(256) void count_bits_kernel(const uint8_t* in, int64_t bit_offset, int64_t nbits, u64* out) {
+  u64 local = 0;
+  const int64_t words = (nbits + 31) >> 5;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < words; k += (int64_t)gridDim.x * 256) {
+    const int cnt = (int)(nbits - 32 * k < 32 ? nbits - 32 * k : 32);
+    const int64_t sb = bit_offset + 32 * k;
+    const uint8_t* q = in + (sb >> 3);
+    const int sh = (int)(sb & 7);
+    const int need = (sh + cnt + 7) >> 3;
+    u64 raw = 0;
+    for (int t = 0; t < need; ++t) raw |= (u64)q[t] << (8 * t);
+    uint32_t v = (uint32_t)(raw >> sh);
+    if (cnt < 32) v &= (1u << cnt) - 1u;
+    local += __popc(v);
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+static int ipc_grid(int64_t items) { const int64_t g = (items + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+hipError_t launch_rebase_offsets(const int32_t* in, int32_t* out, int64_t n_plus_1, hipStream_t stream) {
+  hipLaunchKernelGGL(rebase_offsets_kernel, dim3(ipc_grid(n_plus_1)), dim3(256), 0, stream, in, out, n_plus_1);
+  return hipGetLastError();
+}
+hipError_t launch_bit_shift_copy(const uint8_t* in, int64_t bit_offset, int64_t nbits, uint32_t* out, hipStream_t stream) {
+  hipLaunchKernelGGL(bit_shift_copy_kernel, dim3(ipc_grid((nbits + 31) / 32)), dim3(256), 0, stream, in, bit_offset, nbits, out);
+  return hipGetLastError();
+}
+hipError_t launch_count_bits(const uint8_t* in, int64_t bit_offset, int64_t nbits, u64* out, hipStream_t stream) {
+  hipLaunchKernelGGL(count_bits_kernel, dim3(ipc_grid((nbits + 31) / 32)), dim3(256), 0, stream, in, bit_offset, nbits, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream) {   // 8192-row tiles
   hipLaunchKernelGGL((utf8_filter_kernel<1024, 8>), dim3(grid), dim3(1024), 0, stream, p);
   return hipGetLastError();

@@ -373,6 +373,78 @@ def plan_describe(schema: pa.Schema, table_aliases: Optional[Sequence[Sequence[s
     return text
 
 
+class IpcEncoded:
+    """`chq_record_to_ipc`: an Arrow IPC stream in three parts -- `header` (host bytes: Schema message + the RecordBatch
+    message's metadata), the body (`body_address`, `body_len`; in HBM unless `body_on_device` is False) and the 8-byte
+    end-of-stream marker.  `to_bytes()` is the complete stream (host bodies only)."""
+
+    def __init__(self, ctx: Context, msg: "L.IpcMessage"):
+        self.ctx = ctx
+        self._msg = msg
+        self.header = C.string_at(msg.header, msg.header_len)
+        self.body_address = msg.body or 0
+        self.body_len = msg.body_len
+        self.body_on_device = msg.body_device_type == L.ARROW_DEVICE_ROCM
+        self.end_of_stream = bytes(msg.end_of_stream)
+
+    def to_bytes(self) -> bytes:
+        if self.body_on_device:
+            raise ValueError("the body lives in HBM: ask for body_on_device=False, or move it with RCCL / a peer copy")
+        return self.header + C.string_at(self.body_address, self.body_len) + self.end_of_stream
+
+    def release(self) -> None:
+        if self._msg is not None and self._msg.release:
+            C.CFUNCTYPE(None, C.c_void_p)(self._msg.release)(C.addressof(self._msg))
+        self._msg = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def record_to_ipc(record: Record, *, ctx: Optional[Context] = None, body_on_device: bool = False) -> IpcEncoded:
+    """Arrow IPC stream encoding of one batch (messages/exchange.rs:145-197 of the reference) with the body assembled
+    on the GPU (`chq_record_to_ipc`)."""
+    ctx, src, own_src, _ = _prepare(record, ctx)
+    msg = L.IpcMessage()
+    try:
+        rc = L.lib().chq_record_to_ipc(ctx.handle, C.byref(src.array), C.byref(src.schema),
+                                       L.ARROW_DEVICE_ROCM if body_on_device else L.ARROW_DEVICE_CPU, C.byref(msg))
+    finally:
+        if own_src:
+            src.release()
+    if rc:
+        raise ChqError(rc, ctx.last_error())
+    return IpcEncoded(ctx, msg)
+
+
+def record_from_ipc(stream: bytes, *, ctx: Optional[Context] = None, device_result: bool = True,
+                    body_address: int = 0, body_len: int = 0, body_on_device: bool = True):
+    """Inverse (`chq_record_from_ipc`, messages/exchange.rs:247-276): `stream` is a complete Arrow IPC stream, or -- with
+    `body_address` -- only its metadata part, the body being read from that (device or host) address."""
+    ctx = ctx or default_context()
+    out = _CBatch()
+    buf = (C.c_uint8 * len(stream)).from_buffer_copy(stream)
+    rc = L.lib().chq_record_from_ipc(ctx.handle, C.addressof(buf), len(stream), body_address or None, body_len,
+                                     L.ARROW_DEVICE_ROCM if body_on_device else L.ARROW_DEVICE_CPU,
+                                     L.ARROW_DEVICE_ROCM if device_result else L.ARROW_DEVICE_CPU,
+                                     C.byref(out.array), C.byref(out.schema))
+    return _finish(ctx, rc, out, device_result)
+
+
+def ipc_describe(stream: bytes) -> str:
+    """Host half only: the metadata of an Arrow IPC stream as text (`chq_ipc_describe`); needs no GPU."""
+    buf = C.create_string_buffer(1 << 16)
+    data = (C.c_uint8 * max(1, len(stream))).from_buffer_copy(stream or b"\0")
+    rc = L.lib().chq_ipc_describe(C.addressof(data), len(stream), buf, len(buf))
+    text = buf.value.decode(errors="replace")
+    if rc:
+        raise ChqError(rc, text)
+    return text
+
+
 class RecordGroup:
     """A prepared argument block for `filter_records`: the C pointer array over a list of same-schema batches.
     Building it once lets a caller that re-filters the same batches (benchmarks) keep Python out of the call."""

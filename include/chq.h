@@ -227,6 +227,43 @@ chq_status chq_record_copy_to_peer(chq_ctx* src_ctx, chq_ctx* dst_ctx, const str
                                    const struct ArrowSchema* schema, struct ArrowDeviceArray* out,
                                    struct ArrowSchema* out_schema);
 
+/* ---- Arrow IPC with the message body in HBM ------------------------------------------------------------------------ */
+/* The wire format the reference puts a batch in when it leaves the process: an Arrow IPC *stream* -- Schema message,
+ * one RecordBatch message, end-of-stream -- written by arrow::ipc::writer::StreamWriter and read back by
+ * arrow::ipc::reader::StreamReader (src/handlers/message_handler/messages/exchange.rs:145-197, 247-276).  For a batch
+ * that lives on the GPU the two metadata flatbuffers are built on the host and the message BODY (every Arrow buffer,
+ * rebased to offset 0, 64-byte aligned, back to back) is assembled in ONE HBM allocation, so it travels with a single
+ * RCCL send / peer copy, or one D2H copy when it must cross TCP.  The bytes
+ *     header[0 .. header_len)  ++  body[0 .. body_len)  ++  end_of_stream[0 .. 8)
+ * are exactly the stream an Arrow reader expects.  Dictionaries, compression and nested types: CHQ_ERR_NOT_SUPPORTED. */
+typedef struct chq_ipc_message {
+  const uint8_t* header;      /* host memory: Schema message + framing and metadata of the RecordBatch message */
+  int64_t header_len;
+  const void* body;           /* HBM (ARROW_DEVICE_ROCM) or host memory (ARROW_DEVICE_CPU), see body_device_type */
+  int64_t body_len;
+  int32_t body_device_type;
+  int32_t body_device_id;
+  uint8_t end_of_stream[8];   /* 0xFFFFFFFF 0x00000000 */
+  void (*release)(struct chq_ipc_message*);
+  void* private_data;
+} chq_ipc_message;
+
+/* `rec`: host or device resident.  `body_device`: ARROW_DEVICE_ROCM (the body stays in HBM) or ARROW_DEVICE_CPU. */
+chq_status chq_record_to_ipc(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                             int body_device, chq_ipc_message* out);
+/* Inverse.  `stream` (host memory) holds the Schema message and the RecordBatch message's metadata; the body is `body`
+ * (in memory of kind `body_device_type`), or -- when `body` is NULL -- follows the metadata inside `stream` itself, i.e.
+ * `stream` is a complete Arrow IPC stream as any Arrow writer produces it.  The body is moved to `out_device` with one
+ * copy; the returned batch owns it. */
+chq_status chq_record_from_ipc(chq_ctx* ctx, const uint8_t* stream, int64_t stream_len, const void* body, int64_t body_len,
+                               int body_device_type, int out_device, struct ArrowDeviceArray* out,
+                               struct ArrowSchema* out_schema);
+
+/* Host half only (no GPU, no context): what the metadata of an Arrow IPC stream says -- "rows R body B body_at P", one
+ * "field <name> <format> nullable=<0|1> nulls=<k>" line per column, one "buffer <offset> <length>" line per buffer.  Used
+ * by the CPU test tier (the flatbuffer reader against pyarrow's writer) and for debugging. */
+chq_status chq_ipc_describe(const uint8_t* stream, int64_t stream_len, char* buf, size_t buf_len);
+
 /* Wrap caller-owned device (or host) buffers as a record batch without copying; the buffers must
  * outlive the returned structs, whose release callbacks free only the descriptors. `format` is an
  * Arrow C format string ("i","f","g","l","b","u", ...). */

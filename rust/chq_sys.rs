@@ -71,6 +71,20 @@ pub struct chq_column_desc {
     pub data: *const c_void,
 }
 
+/// struct chq_ipc_message: an Arrow IPC stream in three parts (header on the host, body in HBM or on the host, end marker)
+#[repr(C)]
+pub struct chq_ipc_message {
+    pub header: *const u8,
+    pub header_len: i64,
+    pub body: *const c_void,
+    pub body_len: i64,
+    pub body_device_type: i32,
+    pub body_device_id: i32,
+    pub end_of_stream: [u8; 8],
+    pub release: Option<unsafe extern "C" fn(*mut chq_ipc_message)>,
+    pub private_data: *mut c_void,
+}
+
 // Every function include/chq.h declares, in header order (tests/test_abi.py checks names and arity against the header).
 #[link(name = "chq")]
 extern "C" {
@@ -151,6 +165,17 @@ extern "C" {
         src_ctx: *mut chq_ctx, dst_ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
     ) -> c_int;
+    /// Arrow IPC stream of one batch, body assembled in one HBM allocation (messages/exchange.rs:145-197)
+    pub fn chq_record_to_ipc(
+        ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema, body_device: c_int,
+        out: *mut chq_ipc_message,
+    ) -> c_int;
+    /// inverse (messages/exchange.rs:247-276); `body` null = the body follows the metadata inside `stream`
+    pub fn chq_record_from_ipc(
+        ctx: *mut chq_ctx, stream: *const u8, stream_len: i64, body: *const c_void, body_len: i64,
+        body_device_type: c_int, out_device: c_int, out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+    pub fn chq_ipc_describe(stream: *const u8, stream_len: i64, buf: *mut c_char, buf_len: usize) -> c_int;
     pub fn chq_wrap_columns(
         ctx: *mut chq_ctx, cols: *const chq_column_desc, n_cols: c_int, n_rows: i64, device_type: c_int,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,

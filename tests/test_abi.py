@@ -56,7 +56,7 @@ def test_rust_ffi_declares_every_export_with_the_same_arity():
     for name, n in c_funcs.items():
         assert r_funcs[name] == n, (name, n, r_funcs[name])
     # the repr(C) structs the functions take by pointer
-    for struct in ("ArrowDeviceArray", "chq_select_item", "chq_alias_list", "chq_table_aliases", "chq_call_stats", "chq_column_desc"):
+    for struct in ("ArrowDeviceArray", "chq_select_item", "chq_alias_list", "chq_table_aliases", "chq_call_stats", "chq_column_desc", "chq_ipc_message"):
         assert re.search(r"#\[repr\(C\)\]\s*(?:#\[[^\]]*\]\s*)*pub struct " + struct + r"\b", rust), struct
 
 
