@@ -34,69 +34,117 @@ def all_reduce_counts(counts: Dict[str, int], device=None) -> Dict[str, int]:
     return {k: int(v) for k, v in zip(keys, t.tolist())}
 
 
-def _batch_to_tensors(rec: pa.RecordBatch):
-    """Arrow buffers of a host batch as uint8 tensors + a JSON description (schema, lengths, buffer sizes)."""
-    import torch
-    meta = {"num_rows": rec.num_rows, "schema": rec.schema.serialize().to_pybytes().hex(), "columns": []}
-    tensors = []
-    for col in rec.columns:
-        col = pa.concat_arrays([col]) if col.offset else col    # normalise slices before shipping
-        bufs = col.buffers()
-        sizes = []
-        for b in bufs:
-            if b is None:
-                sizes.append(-1)
-                continue
-            sizes.append(b.size)
-            tensors.append(torch.frombuffer(memoryview(b), dtype=torch.uint8).clone() if b.size else torch.empty(0, dtype=torch.uint8))
-        meta["columns"].append({"null_count": col.null_count, "buffers": sizes})
-    return meta, tensors
+# ---------------------------------------------------------------------------------------------------------------
+# Wire format of one record = the reference's (messages/exchange.rs:180-197): a small envelope -- u8 variant, u64
+# big-endian length, JSON metadata (record id, table aliases) -- followed by an Arrow IPC *stream* (Schema message,
+# one RecordBatch message, end-of-stream).  A host batch travels as ONE byte string (pyarrow writes the stream).  A batch
+# in HBM travels as the envelope + IPC metadata (host bytes, a few hundred) and the IPC *body* as ONE device buffer
+# (`chq_record_to_ipc` assembles it in a single HBM allocation) sent peer to peer by RCCL over the xGMI link of the
+# pair; the receiver wraps it with `chq_record_from_ipc`.  The rows never touch the host.
+# ---------------------------------------------------------------------------------------------------------------
+_VARIANT_SEND_RECORD = 1
 
 
-def send_record(rec: pa.RecordBatch, record_id: int, dst: int, device=None) -> None:
-    """Point-to-point transfer of one record batch (host representation) to rank `dst`."""
+def _envelope(meta: dict, ipc: bytes) -> bytes:
+    import struct
+    m = json.dumps(meta).encode()
+    return struct.pack(">BQ", _VARIANT_SEND_RECORD, len(m)) + m + ipc
+
+
+def _open_envelope(frame: bytes):
+    import struct
+    variant, mlen = struct.unpack(">BQ", frame[:9])
+    if variant != _VARIANT_SEND_RECORD:
+        raise ValueError(f"unexpected exchange message variant {variant}")
+    return json.loads(frame[9:9 + mlen].decode()), frame[9 + mlen:]
+
+
+def _send_bytes(data: bytes, dst: int, device) -> None:
     import torch
     import torch.distributed as dist
-    meta, tensors = _batch_to_tensors(rec)
-    meta["record_id"] = record_id
-    blob = torch.frombuffer(bytearray(json.dumps(meta).encode()), dtype=torch.uint8).to(device) if device is not None else \
-        torch.frombuffer(bytearray(json.dumps(meta).encode()), dtype=torch.uint8)
-    dist.send(torch.tensor([blob.numel()], dtype=torch.int64, device=device), dst)
-    dist.send(blob, dst)
-    for t in tensors:
-        if t.numel():
-            dist.send(t.to(device) if device is not None else t, dst)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+    t = t.to(device) if device is not None else t
+    dist.send(torch.tensor([t.numel()], dtype=torch.int64, device=device), dst)
+    if t.numel():
+        dist.send(t, dst)
 
 
-def recv_record(src: int, device=None) -> Tuple[int, pa.RecordBatch]:
+def _recv_bytes(src: int, device) -> bytes:
     import torch
     import torch.distributed as dist
     n = torch.zeros(1, dtype=torch.int64, device=device)
     dist.recv(n, src)
-    blob = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
-    dist.recv(blob, src)
-    meta = json.loads(blob.cpu().numpy().tobytes().decode())
-    schema = pa.ipc.read_schema(pa.py_buffer(bytes.fromhex(meta["schema"])))
-    arrays = []
-    for field, cm in zip(schema, meta["columns"]):
-        bufs = []
-        for size in cm["buffers"]:
-            if size < 0:
-                bufs.append(None)
-                continue
-            t = torch.zeros(size, dtype=torch.uint8, device=device)
-            if size:
-                dist.recv(t, src)
-            bufs.append(pa.py_buffer(t.cpu().numpy().tobytes()))
-        arrays.append(pa.Array.from_buffers(field.type, meta["num_rows"], bufs, null_count=cm["null_count"]))
-    return meta["record_id"], pa.RecordBatch.from_arrays(arrays, schema=schema)
+    if int(n.item()) == 0:
+        return b""
+    t = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    dist.recv(t, src)
+    return t.cpu().numpy().tobytes()
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# Device-resident exchange: the Arrow buffers of a batch in HBM go peer to peer (RCCL send/recv over the xGMI link
-# between the two GPUs) without touching the host; only the small JSON header is built on the CPU.
-# ---------------------------------------------------------------------------------------------------------------
-_WIDTHS = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "l": 8, "L": 8, "e": 2, "f": 4, "g": 8}
+def record_to_stream(rec: pa.RecordBatch) -> bytes:
+    """Arrow IPC stream of a host batch (what arrow::ipc::writer::StreamWriter produces in the reference)"""
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, rec.schema) as w:
+        w.write_batch(rec)
+    return sink.getvalue().to_pybytes()
+
+
+def stream_to_record(stream: bytes) -> pa.RecordBatch:
+    t = pa.ipc.open_stream(stream).read_all()
+    batches = t.combine_chunks().to_batches()
+    if len(batches) > 1:
+        raise ValueError("received multiple record batches")       # exchange.rs:262-266
+    return batches[0] if batches else pa.RecordBatch.from_pylist([], schema=t.schema)
+
+
+def send_record(rec: pa.RecordBatch, record_id: int, dst: int, device=None, table_aliases=None) -> None:
+    """Point-to-point transfer of one host record batch to rank `dst`: one framed byte string."""
+    _send_bytes(_envelope({"record_id": record_id, "table_aliases": table_aliases}, record_to_stream(rec)), dst, device)
+
+
+def recv_record(src: int, device=None) -> Tuple[int, pa.RecordBatch]:
+    meta, stream = _open_envelope(_recv_bytes(src, device))
+    recv_record.last_table_aliases = meta.get("table_aliases")
+    return meta["record_id"], stream_to_record(stream)
+
+
+recv_record.last_table_aliases = None
+
+
+def send_device_record(rec, record_id: int, dst: int, table_aliases=None) -> None:
+    """Point-to-point transfer of a batch that lives in HBM to the GPU of rank `dst` (backend "nccl" = RCCL): the IPC
+    metadata in the envelope, the IPC body as one device buffer."""
+    import torch
+    import torch.distributed as dist
+    from ..record_utils import record_to_ipc
+    device = torch.device("cuda", rec.ctx.device_id)
+    enc = record_to_ipc(rec, ctx=rec.ctx, body_on_device=True)
+    try:
+        _send_bytes(_envelope({"record_id": record_id, "table_aliases": table_aliases, "body_len": enc.body_len}, enc.header), dst, device)
+        if enc.body_len:
+            dist.send(_as_tensor(enc.body_address, enc.body_len, enc, device), dst)
+        # With RCCL the send is only enqueued (on torch's current stream) and the tensor is a zero-copy view of the
+        # library's HBM buffer, not caching-allocator memory: drain it before the buffer goes back to the pool.
+        torch.cuda.current_stream(device).synchronize()
+    finally:
+        enc.release()
+
+
+def recv_device_record(src: int, ctx):
+    """-> (record_id, DeviceRecordBatch, table_aliases); the body lands in this rank's HBM and stays there."""
+    import torch
+    import torch.distributed as dist
+    from ..record_utils import record_from_ipc
+    device = torch.device("cuda", ctx.device_id)
+    meta, header = _open_envelope(_recv_bytes(src, device))
+    body_len = int(meta["body_len"])
+    body = torch.empty(max(body_len, 1) + 64, dtype=torch.uint8, device=device)
+    if body_len:
+        dist.recv(body[:body_len], src)
+    # the batch is handed to a chq context that launches on its OWN stream: every byte must have landed first
+    torch.cuda.current_stream(device).synchronize()
+    rec = record_from_ipc(header, ctx=ctx, device_result=True, body_address=body.data_ptr(), body_len=body_len, body_on_device=True)
+    return meta["record_id"], rec, meta.get("table_aliases")
 
 
 class _HbmRange:
@@ -112,116 +160,6 @@ def _as_tensor(ptr: int, nbytes: int, owner, device):
     if nbytes == 0 or not ptr:
         return torch.empty(0, dtype=torch.uint8, device=device)
     return torch.as_tensor(_HbmRange(ptr, nbytes, owner), device=device)
-
-
-def _fixed_width(fmt: str) -> int:
-    if fmt in _WIDTHS:
-        return _WIDTHS[fmt]
-    if fmt.startswith("w:"):
-        return int(fmt[2:])
-    if fmt.startswith("d:"):
-        parts = fmt[2:].split(",")
-        return int(parts[2]) // 8 if len(parts) == 3 else 16
-    if fmt in ("tdD", "tts", "ttm"):
-        return 4
-    if fmt in ("tdm", "ttu", "ttn") or fmt.startswith("ts") or fmt.startswith("tD"):
-        return 8
-    raise ValueError(f"no fixed width for Arrow format {fmt!r}")
-
-
-def device_record_to_tensors(rec, device=None):
-    """(header, tensors): zero-copy uint8 views of every Arrow buffer of a DeviceRecordBatch, in header order.
-    Buffers are sent from element 0 to offset + length, so the receiver keeps the same Arrow offsets."""
-    import torch
-    device = device if device is not None else torch.device("cuda", rec.ctx.device_id)
-    header = {"num_rows": rec.num_rows, "columns": []}
-    tensors = []
-    for col in rec.describe_columns():
-        end = col["offset"] + rec.num_rows
-        fmt = col["format"]
-        sizes = {"validity": 0, "values": 0, "data": 0}
-        if col["validity"] and col["null_count"] != 0:
-            sizes["validity"] = (end + 7) // 8
-        if fmt == "b":
-            sizes["values"] = (end + 7) // 8
-        elif fmt == "u":
-            # offsets stay absolute: only the bytes the logical rows use, [offsets[offset], offsets[end]), are sent and
-            # the receiver rebases its data pointer by the first offset
-            sizes["values"] = 4 * (end + 1)
-            if col["values"] and rec.num_rows:
-                first = int(_as_tensor(col["values"] + 4 * col["offset"], 4, rec, device).view(torch.int32).item())
-                last = int(_as_tensor(col["values"] + 4 * end, 4, rec, device).view(torch.int32).item())
-                sizes["data"] = last - first
-                col = dict(col, data=col["data"] + first, data_base=first)
-        else:
-            sizes["values"] = _fixed_width(fmt) * end
-        for key in ("validity", "values", "data"):
-            if sizes[key]:
-                tensors.append(_as_tensor(col[key], sizes[key], rec, device))
-        header["columns"].append({k: col[k] for k in ("name", "format", "nullable", "null_count", "offset")} |
-                                 {"sizes": sizes, "data_base": col.get("data_base", 0)})
-    return header, tensors
-
-
-def tensors_to_device_record(header, tensors, ctx):
-    """Inverse of `device_record_to_tensors`: wraps the received tensors (kept alive by the batch) as a DeviceRecordBatch."""
-    from ..record_utils import DeviceRecordBatch
-    cols, k = [], 0
-    for c in header["columns"]:
-        d = {key: c[key] for key in ("name", "format", "nullable", "null_count", "offset")}
-        for key in ("validity", "values", "data"):
-            if c["sizes"][key]:
-                d[key] = tensors[k].data_ptr() - (c.get("data_base", 0) if key == "data" else 0)
-                k += 1
-        if c["format"] == "u" and not c["sizes"]["data"]:
-            d["data"] = 0
-        if not c["sizes"]["validity"]:
-            d["null_count"] = 0
-        cols.append(d)
-    return DeviceRecordBatch.from_device_buffers(cols, header["num_rows"], ctx, keepalive=list(tensors))
-
-
-def send_device_record(rec, record_id: int, dst: int, table_aliases=None) -> None:
-    """Point-to-point transfer of a batch that lives in HBM to the GPU of rank `dst` (backend "nccl" = RCCL)."""
-    import torch
-    import torch.distributed as dist
-    header, tensors = device_record_to_tensors(rec)
-    header["record_id"] = record_id
-    header["table_aliases"] = table_aliases
-    device = tensors[0].device if tensors else torch.device("cuda", rec.ctx.device_id)
-    blob = torch.frombuffer(bytearray(json.dumps(header).encode()), dtype=torch.uint8).to(device)
-    dist.send(torch.tensor([blob.numel()], dtype=torch.int64, device=device), dst)
-    dist.send(blob, dst)
-    for t in tensors:
-        dist.send(t, dst)
-    # With RCCL the sends are only enqueued (on torch's current stream).  The tensors are zero-copy views of the batch's
-    # HBM buffers, not caching-allocator memory: once the caller acks the record the buffers may go back to the library's
-    # pool and be reused by a chq call on another stream.  Drain the sends before returning (gloo sends are synchronous).
-    if device.type == "cuda":
-        torch.cuda.current_stream(device).synchronize()
-
-
-def recv_device_record(src: int, ctx):
-    """-> (record_id, DeviceRecordBatch, table_aliases); the buffers land in this rank's HBM and stay there."""
-    import torch
-    import torch.distributed as dist
-    device = torch.device("cuda", ctx.device_id)
-    n = torch.zeros(1, dtype=torch.int64, device=device)
-    dist.recv(n, src)
-    blob = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
-    dist.recv(blob, src)
-    header = json.loads(blob.cpu().numpy().tobytes().decode())
-    tensors = []
-    for c in header["columns"]:
-        for key in ("validity", "values", "data"):
-            if c["sizes"][key]:
-                t = torch.empty(c["sizes"][key] + 16, dtype=torch.uint8, device=device)[: c["sizes"][key]]
-                dist.recv(t, src)
-                tensors.append(t)
-    # the batch is handed to a chq context that launches on its OWN stream with no sync_event: every byte must have
-    # landed before it is wrapped
-    torch.cuda.current_stream(device).synchronize()
-    return header["record_id"], tensors_to_device_record(header, tensors, ctx), header.get("table_aliases")
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -255,8 +193,7 @@ def forward_exchange(ex, operator_id: str, instance_id: int, dst: int, device=No
             send_device_record(record, record_id, dst, aliases)
         else:
             _send_kind(0, dst, device)
-            send_record(record, record_id, dst, device)
-            _send_json(aliases, dst, device)
+            send_record(record, record_id, dst, device, aliases)
         ex.operator_completed_record_processing(operator_id, record_id)
         shipped += 1
     _send_kind(_END_OF_STREAM, dst, device)
@@ -277,7 +214,7 @@ def receive_into_exchange(ex, srcs: Sequence[int], ctx=None, device=None) -> int
                 record_id, record, aliases = recv_device_record(src, ctx)
             else:
                 record_id, record = recv_record(src, device)
-                aliases = _recv_json(src, device)
+                aliases = recv_record.last_table_aliases
             ex.send_record(record_id, record, aliases)
             added += 1
     return added
@@ -304,25 +241,3 @@ def _recv_kind(src: int, device) -> int:
     t = torch.zeros(1, dtype=torch.int64, device=device)
     dist.recv(t, src)
     return int(t.item())
-
-
-def _send_json(obj, dst: int, device) -> None:
-    import torch
-    import torch.distributed as dist
-    blob = torch.frombuffer(bytearray(json.dumps(obj).encode()), dtype=torch.uint8)
-    blob = blob.to(device) if device is not None else blob
-    dist.send(torch.tensor([blob.numel()], dtype=torch.int64, device=device), dst)
-    if blob.numel():
-        dist.send(blob, dst)
-
-
-def _recv_json(src: int, device):
-    import torch
-    import torch.distributed as dist
-    n = torch.zeros(1, dtype=torch.int64, device=device)
-    dist.recv(n, src)
-    if int(n.item()) == 0:
-        return None
-    blob = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
-    dist.recv(blob, src)
-    return json.loads(blob.cpu().numpy().tobytes().decode())

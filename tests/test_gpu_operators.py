@@ -58,24 +58,29 @@ def test_filter_task_groups_queued_records_into_one_launch(tmp_path):
         assert got.to_pydict() == exp.to_pydict(), rid
 
 
-def test_device_batch_round_trips_through_the_exchange_tensors():
-    """operators/distributed.py: the Arrow buffers of a batch in HBM as zero-copy tensors (what RCCL send/recv moves),
-    and back -- every column kind, nulls, a sliced (offset) input; the clone stands in for the wire"""
-    import json
-    from chapterhouseqe_amd.operators.distributed import device_record_to_tensors, tensors_to_device_record
+def test_device_batch_round_trips_through_the_exchange_wire_format():
+    """operators/distributed.py: a batch in HBM as the exchange ships it -- envelope + Arrow IPC metadata (host bytes) and
+    the IPC body as ONE zero-copy device tensor (what RCCL send/recv moves) -- and back: every column kind, nulls, a
+    sliced (offset) input; the clone stands in for the wire"""
+    import torch
+    from chapterhouseqe_amd.operators.distributed import _as_tensor, _envelope, _open_envelope
     from chapterhouseqe_amd.sqlparse import parse_expr
     from .helpers import batches_identical, explain_diff
     from .test_gpu_parity import make_batch
     ctx = chq.Context(0)
+    device = torch.device("cuda", 0)
     for rec in (make_batch(5000, 321).slice(3, 4000), make_batch(70, 5, nulls=False), make_batch(2, 6)):
         dev = chq.DeviceRecordBatch.from_host(rec, ctx)
-        header, tensors = device_record_to_tensors(dev)
-        header = json.loads(json.dumps(header))
-        assert all(t.is_cuda and t.dtype.is_floating_point is False for t in tensors)
-        assert tensors[0].data_ptr() in {c[k] for c in dev.describe_columns() for k in ("validity", "values", "data")}   # zero copy
-        moved = [t.clone() for t in tensors]
-        del tensors
-        back = tensors_to_device_record(header, moved, ctx)
+        enc = chq.record_to_ipc(dev, ctx=ctx, body_on_device=True)
+        frame = _envelope({"record_id": 7, "table_aliases": [["t"]], "body_len": enc.body_len}, enc.header)
+        body = _as_tensor(enc.body_address, enc.body_len, enc, device)
+        assert body.is_cuda and body.data_ptr() == enc.body_address and body.numel() == enc.body_len      # zero copy, ONE buffer
+        moved = body.clone()
+        del body
+        enc.release()
+        meta, header = _open_envelope(frame)
+        assert meta["record_id"] == 7 and meta["table_aliases"] == [["t"]]
+        back = chq.record_from_ipc(header, ctx=ctx, device_result=True, body_address=moved.data_ptr(), body_len=meta["body_len"])
         del moved
         got = back.to_host()
         assert batches_identical(got, rec), explain_diff(got, rec)
@@ -83,6 +88,30 @@ def test_device_batch_round_trips_through_the_exchange_tensors():
         e = parse_expr("f32 > 0.0 and s >= 'ab' or i64 % 3 = 0")
         assert batches_identical(chq.filter_record(back, al, e, ctx=ctx).to_host(), O.filter_record(rec, al, e))
     ctx.close()
+
+
+def test_peer_copy_between_two_contexts():
+    """chq_record_copy_to_peer: the C-ABI data plane for a single-process worker with one context per GPU
+    (hipMemcpyPeerAsync + sync_event).  One GPU here: the "peer" is a second context on the same device; with two or more
+    GPUs the copy crosses xGMI (next test)."""
+    import torch
+    from chapterhouseqe_amd.sqlparse import parse_expr
+    from .helpers import batches_identical, explain_diff
+    from .test_gpu_parity import make_batch
+    src_ctx = chq.Context(0)
+    dst_dev = 1 if torch.cuda.device_count() > 1 else 0
+    dst_ctx = chq.Context(dst_dev)
+    for rec in (make_batch(30_000, 11), make_batch(5000, 12).slice(5, 3000), make_batch(1, 13), make_batch(0, 14)):
+        dev = chq.DeviceRecordBatch.from_host(rec, src_ctx)
+        moved = dev.copy_to_peer(dst_ctx)
+        assert moved.ctx is dst_ctx and moved._cb.array.sync_event            # asynchronous: carries the event to wait on
+        assert moved.column_buffer_address(0, 1) != dev.column_buffer_address(0, 1)
+        al = [[] for _ in range(rec.num_columns)]
+        e = parse_expr("f32 > 0.0 and s >= 'ab' or i64 % 3 = 0")
+        got = chq.filter_record(moved, al, e, ctx=dst_ctx).to_host()          # waits on the sync_event inside the call
+        assert batches_identical(got, O.filter_record(rec, al, e)), explain_diff(got, O.filter_record(rec, al, e))
+        assert batches_identical(moved.to_host(), rec)
+    src_ctx.close(); dst_ctx.close()
 
 
 def _p2p_worker(rank, port, q):
