@@ -134,7 +134,6 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "small_host") ctx->c.opt_small_host = value != 0;
     else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }
     else if (k == "grid_per_cu") ctx->c.opt_grid_per_cu = value;
-    else if (k == "utf8_variant") ctx->c.opt_utf8_variant = value;
     else if (k == "split_rows") ctx->c.opt_split_rows = value;
     else if (k == "group_mode") ctx->c.opt_group_mode = value;
     else if (k == "group_chunk_bytes") { if (value < 1 || value > (1ll << 30)) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "group_chunk_bytes must be 1..2^30"}; ctx->c.opt_group_chunk_bytes = value; }

@@ -961,8 +961,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       Column& o = out.cols[ci];
       const int64_t cap = (int64_t)hs->utf8_ends[2 * (k - u0) + 1] - hs->utf8_ends[2 * (k - u0)];
       const bool fused = cap <= mask_len * 24;
-      const bool small_tiles = fused && ctx.opt_utf8_variant == 1;
-      const int64_t utile_rows = fused ? (small_tiles ? 4096 : 8192) : 2048;
+      const int64_t utile_rows = fused ? 8192 : 2048;
       const int64_t utiles = (mask_len + utile_rows - 1) / utile_rows;
       auto offb = make_device_buffer((size_t)(total + 2) * 4, ctx.device);
       auto db = make_device_buffer((size_t)cap + 16, ctx.device);
@@ -977,8 +976,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       up.total_bytes = &ds->counters[kNullPerRound + (k - u0)];   // counters[16..23]: byte totals
       up.rows_out = total;
       if (fused) {
-        if (small_tiles) check_hip(launch_utf8_filter_small(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 4), ctx.stream), "launch utf8_filter_kernel");
-        else check_hip(launch_utf8_filter(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 2), ctx.stream), "launch utf8_filter_kernel");
+        check_hip(launch_utf8_filter(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 2), ctx.stream), "launch utf8_filter_kernel");
         ++ctx.stats.launches;
       } else {
         check_hip(launch_utf8_offsets(up, (int)std::min<int64_t>(utiles, (int64_t)ctx.num_cus * 8), ctx.stream), "launch utf8_offsets_kernel");

@@ -21,7 +21,6 @@ hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, 
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
-hipError_t launch_utf8_filter_small(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);
 hipError_t launch_split_bounds(const SplitBoundsParams& p, hipStream_t stream);
@@ -119,7 +118,6 @@ struct Context {
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
   int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots
-  int64_t opt_utf8_variant = 0;     // short-string pass: 0 = 8 192-row tiles, 1 = 4 096-row tiles (two workgroups per CU)
   int64_t opt_fuse = 1;             // chq_filter_project_record's single-pass kernel: 0 never, 1 when it moves clearly fewer bytes, 2 whenever possible
   int64_t opt_grid_per_cu = 0;
   int64_t opt_split_rows = 1 << 20;   // batches at least this long run their complete tiles in the FULL-only kernels

@@ -1349,7 +1349,6 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
 // ------------------------------------------------------------------------------------------------
 template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
-  constexpr int NW = BLOCK / 64;
   constexpr int64_t TILE = (int64_t)BLOCK * R;
   __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1978,10 +1977,6 @@ hipError_t launch_count_bits(const uint8_t* in, int64_t bit_offset, int64_t nbit
 
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream) {   // 8192-row tiles
   hipLaunchKernelGGL((utf8_filter_kernel<1024, 8>), dim3(grid), dim3(1024), 0, stream, p);
-  return hipGetLastError();
-}
-hipError_t launch_utf8_filter_small(const Utf8Params& p, int grid, hipStream_t stream) {   // 4096-row tiles, two workgroups per CU
-  hipLaunchKernelGGL((utf8_filter_kernel<512, 8>), dim3(grid), dim3(512), 0, stream, p);
   return hipGetLastError();
 }
 hipError_t launch_utf8_offsets(const Utf8Params& p, int grid, hipStream_t stream) {   // 2048-row tiles
