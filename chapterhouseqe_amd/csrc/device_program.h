@@ -135,6 +135,20 @@ struct ProgramBlock {
   uint8_t fast_opd[MAX_INSTR];   // FAST_UOPS: FastOperand per instruction
 };
 
+// A Utf8 column filtered inside filter_fused_kernel (single-batch launches only): P(i) adds up the byte lengths of the
+// tile's selected rows, a second chained scan (its own status words, resolved by its own wave while wave 0 resolves the
+// row scan) gives the tile's first output byte, and C(i) writes the new offsets and copies the bytes.  Byte totals
+// stay below 2^31 (int32 offsets), output capacity = the column's input byte span.
+constexpr int MAX_FOLD_UTF8 = 2;
+struct Utf8Fold {
+  const int32_t* in_offsets;   // at row 0
+  const uint8_t* in_data;
+  int32_t* out_offsets;        // [rows_out + 1]
+  uint8_t* out_data;
+  u64* status;                 // per tile, like FilterParams::status; zeroed before launch
+  u64* total_bytes;            // out
+};
+
 struct FilterParams {
   int64_t nrows;          // rows the mask covers
   int64_t tile_begin;     // this launch handles tiles [tile_begin, tile_end); the tail tile of a batch (the only one
@@ -148,7 +162,7 @@ struct FilterParams {
   int16_t n_out;
   int16_t n_stash;        // program column-refs stash_refs[0..n_stash) keep their raw tile values in LDS between P and C;
   int8_t stash_refs[4];   // (MAX_STASH used) those columns are outs[n_out - n_stash ..] and are copied from LDS instead of fetched again
-  int32_t pad0;
+  int32_t n_utf8;         // Utf8 columns filtered inside this launch (utf8[0..n_utf8), MAX_FOLD_UTF8): see Utf8Fold
   int32_t pad1;
   // Batch-group launch (chq_filter_records): many batches of one schema, one launch, one dense compaction.  Tiles never
   // straddle batches; row `tile` of this table (group_stride words) = { first row of the tile inside its batch, rows of
@@ -163,6 +177,7 @@ struct FilterParams {
   int32_t group_wpb;
   int32_t group_nb;
   u64* group_batch_end;
+  Utf8Fold utf8[MAX_FOLD_UTF8];
   ProgramBlock pb;
   OutCol outs[MAX_OUT];
 };

@@ -1516,7 +1516,8 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     chq_call_stats acc{};
     for (size_t k = 0; k + 1 < cuts.size(); ++k) {
       const size_t b0 = cuts[k], b1 = cuts[k + 1];
-      Batch cat = concat_device_batches(ctx, recs, b0, b1, utf8_cols, ubytes);
+      // (a chunk of one batch -- e.g. a 2 GB Utf8 column on its own -- is filtered in place: nothing to join)
+      Batch cat = b1 - b0 == 1 ? to_device(ctx, recs[b0]) : concat_device_batches(ctx, recs, b0, b1, utf8_cols, ubytes);
       SplitRequest split;
       int64_t at = 0;
       for (size_t b = b0; b < b1; ++b) { split.starts.push_back(at); at += recs[b].nrows; }

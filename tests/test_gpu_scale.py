@@ -111,3 +111,73 @@ def test_reference_sized_batches_full_size_group(rows_per_batch, nb):
     out.release()
     grp.release()
     ctx.close()
+
+
+def test_reference_schema_group_full_size():
+    """the reference's own schema in its own batch size, resident in HBM, at scale: 12 500 x 10 000-row batches (1 GB of
+    string bytes: the most one joined Utf8 column can hold with int32 offsets) through ONE chq_filter_records_coalesced
+    call -- per-batch counts, order, ids and the Float32 column bit for bit against torch, string bytes by checksum"""
+    import torch
+    dev = torch.device("cuda", 0)
+    nb, rpb, L8 = 12_500, 10_000, 8
+    n = nb * rpb
+    g = torch.Generator(device=dev); g.manual_seed(0xFEED)
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    chars = torch.randint(ord("a"), ord("z") + 1, (n * L8,), dtype=torch.uint8, device=dev, generator=g)
+    offs = (torch.arange(rpb + 1, dtype=torch.int64, device=dev) * L8).to(torch.int32)      # batch-local offsets, shared
+    v2 = torch.empty(n, dtype=torch.float32, device=dev).uniform_(0, 100, generator=g)
+    ctx = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    recs = [chq.DeviceRecordBatch.from_device_pointers(
+        [("id", "i", ids.data_ptr() + 4 * b * rpb), ("value1", "u", offs.data_ptr(), chars.data_ptr() + L8 * b * rpb),
+         ("value2", "f", v2.data_ptr() + 4 * b * rpb)], rpb, ctx=ctx) for b in range(nb)]
+    grp = chq.RecordGroup(recs, ctx)
+    out, rows = chq.filter_records_coalesced(grp, [[], [], []], parse_expr("value2 > 50.0 and id % 2 = 0"), ctx=ctx)
+    mask = (v2 > 50.0) & (ids % 2 == 0)
+    exp_rows = mask.view(nb, rpb).sum(dim=1)
+    assert torch.equal(torch.tensor(rows, dtype=torch.int64), exp_rows.cpu())
+    m = int(exp_rows.sum().item())
+    assert out.num_rows == m and ctx.last_stats()["launches"] <= 8
+    got_ids = torch.empty(m, dtype=torch.int32, device=dev); _dtod(got_ids, out.column_buffer_address(0, 1), m * 4)
+    got_v2 = torch.empty(m, dtype=torch.float32, device=dev); _dtod(got_v2, out.column_buffer_address(2, 1), m * 4)
+    assert torch.equal(got_ids, torch.masked_select(ids, mask))
+    assert torch.equal(got_v2.view(torch.int32), torch.masked_select(v2, mask).view(torch.int32))
+    got_offs = torch.empty(m + 1, dtype=torch.int32, device=dev); _dtod(got_offs, out.column_buffer_address(1, 1), (m + 1) * 4)
+    assert torch.equal(got_offs.to(torch.int64), torch.arange(m + 1, dtype=torch.int64, device=dev) * L8)     # 8 bytes per kept row
+    got_chars = torch.empty(m * L8, dtype=torch.uint8, device=dev); _dtod(got_chars, out.column_buffer_address(1, 2), m * L8)
+    exp_chars = chars.view(n, L8)[mask]
+    assert torch.equal(got_chars.view(m, L8), exp_chars)
+    out.release(); grp.release(); ctx.close()
+
+
+def test_config4_100m_rows_as_five_batches_in_one_group():
+    """BASELINE config 4 at its full 100 M rows: id:Int32, value1:Utf8(100), value2:Float32.  One Arrow Utf8 array holds
+    < 2 GiB of bytes (int32 offsets), so 100 M rows are five 20 M-row batches; ONE chq_filter_records call filters them
+    (`id > n/2` on batch-local ids) -- counts, ids, and a checksum of the copied string bytes against torch"""
+    import torch
+    dev = torch.device("cuda", 0)
+    nb, rpb, L = 5, 20_000_000, 100
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    ids = torch.arange(rpb, dtype=torch.int32, device=dev)                                   # the same ids in every batch
+    offs = (torch.arange(rpb + 1, dtype=torch.int64, device=dev) * L).to(torch.int32)
+    ctx = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    chars, v2s, recs = [], [], []
+    for b in range(nb):
+        c = torch.randint(ord("a"), ord("z") + 1, (rpb * L,), dtype=torch.uint8, device=dev, generator=g)
+        v = torch.empty(rpb, dtype=torch.float32, device=dev).uniform_(0, 100, generator=g)
+        chars.append(c); v2s.append(v)
+        recs.append(chq.DeviceRecordBatch.from_device_pointers(
+            [("id", "i", ids.data_ptr()), ("value1", "u", offs.data_ptr(), c.data_ptr()), ("value2", "f", v.data_ptr())], rpb, ctx=ctx))
+    outs = chq.filter_records(recs, [[], [], []], parse_expr(f"id > {rpb // 2}"), ctx=ctx)
+    assert len(outs) == nb
+    keep = rpb - rpb // 2 - 1
+    for b, o in enumerate(outs):
+        assert o.num_rows == keep
+        got_ids = torch.empty(keep, dtype=torch.int32, device=dev); _dtod(got_ids, o.column_buffer_address(0, 1), keep * 4)
+        assert torch.equal(got_ids, ids[rpb // 2 + 1:])
+        got_chars = torch.empty(keep * L, dtype=torch.uint8, device=dev); _dtod(got_chars, o.column_buffer_address(1, 2), keep * L)
+        assert torch.equal(got_chars, chars[b][(rpb // 2 + 1) * L:])
+        got_v = torch.empty(keep, dtype=torch.float32, device=dev); _dtod(got_v, o.column_buffer_address(2, 1), keep * 4)
+        assert torch.equal(got_v, v2s[b][rpb // 2 + 1:])
+        del got_ids, got_chars, got_v
+        o.release()
+    ctx.close()
