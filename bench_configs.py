@@ -155,19 +155,18 @@ def main():
             ob = st1["bytes_read_alg"] + st1["bytes_written_alg"]
             one_pass = {"kernel_ms": ok_ms[len(ok_ms) // 2], "wall_ms": ow_ms[len(ow_ms) // 2], "alg_bytes": ob, "launches": st1["launches"],
                         "GBps": ob / (ok_ms[len(ok_ms) // 2] * 1e-3) / 1e9, "frac_of_8TBps": ob / (ok_ms[len(ok_ms) // 2] * 1e-3) / 1e9 / HBM_PEAK}
+        # the library's own count: every fixed-width input byte once, the selected output bytes once;
+        # Utf8: 4 B of offsets per row read by two passes, the SELECTED rows' bytes read and written, 4 B of new offsets
         alg = st["bytes_read_alg"] + st["bytes_written_alg"]
-        # Utf8 / Boolean columns are compacted by follow-up kernels whose bytes the library does not count: add them
-        str_bytes = 0
-        for item in spec:
-            if item[1] == "utf8":
-                str_bytes += n * (4 + item[2]) + rows_out * (4 + item[2])
+        has_utf8 = any(item[1] == "utf8" for item in spec)
+        one_kernel = st["launches"] <= 2          # main kernel (+ its tail-tile launch): the kernel time covers the whole call's bytes
         r = {"case": name, "rows": n, "rows_out": rows_out, "selectivity": rows_out / n, "where": where, "select": select,
              "filter_kernel_ms": fk[len(fk) // 2], "filter_wall_ms": wall[len(wall) // 2], "launches": st["launches"],
-             "alg_bytes_fixed_width": alg, "alg_bytes_strings": str_bytes,
-             "fused_kernel_GBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9,
-             "whole_filter_GBps": (alg + str_bytes) / (wall[len(wall) // 2] * 1e-3) / 1e9,
+             "alg_bytes": alg,
+             "fused_kernel_GBps": alg / (fk[len(fk) // 2] * 1e-3) / 1e9 if one_kernel or not has_utf8 else None,
+             "whole_filter_GBps": alg / (wall[len(wall) // 2] * 1e-3) / 1e9,
              "rows_per_s_wall": n / (wall[len(wall) // 2] * 1e-3), "validated_rows": m, "note": note}
-        r["fused_kernel_frac_of_8TBps"] = r["fused_kernel_GBps"] / HBM_PEAK
+        r["fused_kernel_frac_of_8TBps"] = r["fused_kernel_GBps"] / HBM_PEAK if r["fused_kernel_GBps"] else None
         r["whole_filter_frac_of_8TBps"] = r["whole_filter_GBps"] / HBM_PEAK
         if pk:
             r["project_wall_ms"] = pk[len(pk) // 2]

@@ -130,6 +130,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     if (k == "tile_kind") { if (value < -1 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "tile_kind must be -1..2"}; ctx->c.opt_tile_kind = value; }
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
+    else if (k == "fold_utf8") ctx->c.opt_fold_utf8 = value != 0;
     else if (k == "stash") { if (value < -1 || value > MAX_STASH) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "stash must be -1..2"}; ctx->c.opt_stash = value; }
     else if (k == "small_host") ctx->c.opt_small_host = value != 0;
     else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }

@@ -364,6 +364,7 @@ Column copy_column(Context& ctx, const Column& c, Dir dir, int peer_device = -1)
     const int64_t nb = (int64_t)ends[1] - ends[0];
     auto db = copy_bytes(ctx, c.data ? c.data + ends[0] : nullptr, c.data ? nb : 0, dir);
     o.data = (const uint8_t*)db->ptr - ends[0];   // offsets stay absolute
+    o.data_bytes = nb;
     o.owned.push_back(db);
   } else {
     auto b = copy_bytes(ctx, c.values ? c.values + (int64_t)c.width * base : nullptr, c.values ? (int64_t)c.width * (n + phase) : 0, dir);
@@ -461,6 +462,7 @@ struct Scratch {   // header of ctx.small (device) and layout of ctx.pinned (hos
   unsigned long long total_bytes;
   unsigned long long counters[24];
   int32_t utf8_ends[16];              // first / last input offset of each Utf8 column (output byte capacity)
+  unsigned long long fold_bytes[MAX_FOLD_UTF8];   // output bytes of the Utf8 columns filtered inside the main kernel
 };
 constexpr size_t kPerPass = 24;
 constexpr size_t kHeader = 512;       // status words start here
@@ -804,6 +806,36 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     else fixed_cols.push_back((int)i);
     if (c.validity && c.null_count != 0) nullable_cols.push_back((int)i);
   }
+  Scratch* hs = (Scratch*)ctx.pinned;
+  // Utf8 columns of short strings are filtered inside the main kernel (device_program.h: Utf8Fold).  Their output
+  // capacity is the input byte span: known when the library built the column itself (staged, joined, decoded), one
+  // 8-byte read-back otherwise.
+  std::vector<int> fold_cols; std::vector<int64_t> fold_cap;
+  if (ctx.opt_fold_utf8 && tile_kind != 2 && !utf8_cols.empty() && mask_len == nrows) {
+    const size_t ncand = std::min<size_t>(MAX_FOLD_UTF8, utf8_cols.size());
+    std::vector<int64_t> cap(ncand, -1);
+    bool unknown = false;
+    for (size_t k = 0; k < ncand; ++k) { cap[k] = rec.cols[utf8_cols[k]].data_bytes; unknown |= cap[k] < 0; }
+    if (unknown) {
+      GatherParams gp{};
+      for (size_t k = 0; k < ncand; ++k) {
+        const int32_t* offs = (const int32_t*)rec.cols[utf8_cols[k]].values0();
+        gp.src[2 * k] = offs; gp.src[2 * k + 1] = offs + mask_len;
+      }
+      gp.n = (int32_t)(2 * ncand); gp.dst = ds->utf8_ends;
+      check_hip(launch_gather_i32(gp, ctx.stream), "launch gather_i32_kernel");
+      check_hip(hipMemcpyAsync(hs->utf8_ends, ds->utf8_ends, sizeof(hs->utf8_ends), hipMemcpyDeviceToHost, ctx.stream), "read back");
+      check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+      for (size_t k = 0; k < ncand; ++k) cap[k] = (int64_t)hs->utf8_ends[2 * k + 1] - hs->utf8_ends[2 * k];
+    }
+    std::vector<int> rest;
+    for (size_t k = 0; k < utf8_cols.size(); ++k) {
+      if (k < ncand && cap[k] <= mask_len * 24) { fold_cols.push_back(utf8_cols[k]); fold_cap.push_back(cap[k]); }
+      else rest.push_back(utf8_cols[k]);
+    }
+    utf8_cols.swap(rest);
+  }
+  std::vector<BufferPtr> fold_status;
   const bool need_followup = !bool_cols.empty() || !utf8_cols.empty() || !nullable_cols.empty() || (int)fixed_cols.size() > MAX_OUT ||
                              (split && !split->starts.empty());
   const int64_t ngroups = (mask_len + 63) / 64;
@@ -853,6 +885,25 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       ++n;
     }
     p.n_out = (int16_t)n;
+    if (first) {
+      for (size_t u = 0; u < fold_cols.size(); ++u) {
+        const Column& c = rec.cols[fold_cols[u]];
+        Column& o = out.cols[fold_cols[u]];
+        auto offb = make_device_buffer((size_t)(mask_len + 2) * 4, ctx.device);
+        auto db = make_device_buffer((size_t)fold_cap[u] + 16, ctx.device);
+        auto st = make_device_buffer((size_t)(ntiles + 1) * 8, ctx.device);
+        check_hip(hipMemsetAsync(st->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset byte-scan status");
+        fold_status.push_back(st);
+        Utf8Fold& f = p.utf8[u];
+        f.in_offsets = (const int32_t*)c.values0(); f.in_data = c.data;
+        f.out_offsets = (int32_t*)offb->ptr; f.out_data = (uint8_t*)db->ptr;
+        f.status = (u64*)st->ptr; f.total_bytes = &ds->fold_bytes[u];
+        o.values = (const uint8_t*)offb->ptr; o.owned.push_back(offb);
+        o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
+        ctx.stats.bytes_read_alg += mask_len * 8;   // offsets, by both phases (as the separate Utf8 pass counts them)
+      }
+      p.n_utf8 = (int32_t)fold_cols.size();
+    }
     if (first) check_hip(hipMemsetAsync(ds, 0, kHeader + (size_t)(ntiles + 1) * 8, ctx.stream), "memset scratch + status");
     else {
       check_hip(hipMemsetAsync(ds, 0, kPerPass, ctx.stream), "memset scratch");
@@ -880,7 +931,6 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     first = false;
   } while (next_fixed < fixed_cols.size());
 
-  Scratch* hs = (Scratch*)ctx.pinned;
   BufferPtr split_dev;
   if (split && !split->starts.empty()) {   // output position of every concatenated input batch
     const size_t n = split->starts.size();
@@ -916,6 +966,11 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   out.nrows = total;
   ctx.stats.rows_out = total; ctx.stats.tiles = ntiles;
   for (int ci : fixed_cols) { out.cols[ci].length = total; ctx.stats.bytes_written_alg += total * out.cols[ci].width; }
+  for (size_t u = 0; u < fold_cols.size(); ++u) {
+    Column& o = out.cols[fold_cols[u]];
+    o.length = total; o.data_bytes = (int64_t)hs->fold_bytes[u];
+    ctx.stats.bytes_read_alg += o.data_bytes; ctx.stats.bytes_written_alg += (total + 1) * 4 + o.data_bytes;
+  }
 
   if (need_followup) {
     const int fgrid = (int)std::min<int64_t>((ngroups + 31) / 32, (int64_t)ctx.num_cus * 8);
@@ -992,6 +1047,11 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
       Column& o = out.cols[nullable_cols[k]];
       o.null_count = (int64_t)hs->counters[k - n0];
       if (o.null_count == 0) o.validity = nullptr;   // arrow drops an all-valid null buffer
+    }
+    for (size_t k = u0; k < u1; ++k) {   // offsets read by both passes, selected bytes read and written, new offsets
+      Column& o = out.cols[utf8_cols[k]];
+      o.data_bytes = (int64_t)hs->counters[kNullPerRound + (k - u0)];
+      ctx.stats.bytes_read_alg += mask_len * 8 + o.data_bytes; ctx.stats.bytes_written_alg += (total + 1) * 4 + o.data_bytes;
     }
     n0 = n1; u0 = u1;
     }
@@ -1342,6 +1402,7 @@ Batch concat_device_batches(Context& ctx, const std::vector<Batch>& recs, size_t
       check_hip(launch_concat(cp, 2, grid, ctx.stream), "launch concat_utf8_kernel");
       o.values = (const uint8_t*)ob->ptr; o.owned.push_back(ob);
       o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
+      o.data_bytes = total_bytes[c];
     } else {
       auto vb = make_device_buffer((size_t)total * c0.width + 16, ctx.device);
       cp.dst = vb->ptr; cp.width = c0.width;

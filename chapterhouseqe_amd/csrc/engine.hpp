@@ -90,6 +90,7 @@ struct Column {
   const uint8_t* validity = nullptr;
   const uint8_t* values = nullptr;   // fixed: values buffer; bool: bitmap; utf8: int32 offsets buffer
   const uint8_t* data = nullptr;     // utf8 bytes
+  int64_t data_bytes = -1;           // utf8: bytes the offsets of rows [offset, offset+length] span, when whoever built the column knew (else -1)
   std::vector<BufferPtr> owned;      // keeps staged / produced buffers alive
 
   // derived views (element 0 = first logical row)
@@ -117,6 +118,7 @@ struct Context {
   int64_t opt_tile_kind = -1;       // -1 auto
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
+  int64_t opt_fold_utf8 = 1;        // short-string Utf8 columns are filtered inside filter_fused_kernel (0: always the separate Utf8 pass)
   int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots
   int64_t opt_fuse = 1;             // chq_filter_project_record's single-pass kernel: 0 never, 1 when it moves clearly fewer bytes, 2 whenever possible
   int64_t opt_grid_per_cu = 0;

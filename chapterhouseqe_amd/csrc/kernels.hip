@@ -146,17 +146,33 @@ __device__ __forceinline__ u64 lookback_exclusive_wide(const u64* status, int64_
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-// inclusive prefix sum over the 64 lanes of a wave on the DPP network (no LDS traffic): Kogge-Stone inside each row of
-// 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then lane 15 of rows 0 / 2 is added to
-// rows 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-  return v;
+// Inclusive prefix sums over the 64 lanes of a wave on the DPP network (no LDS traffic): Kogge-Stone inside each row of
+// 16 lanes (row_shr 1, 2, 4, 8; lanes shifted in from outside the row add 0), then lane 15 of rows 0 / 2 is added to
+// rows 1 / 3 (row_bcast:15) and lane 31 to rows 2 and 3 (row_bcast:31).
+// Two independent scans interleaved: each DPP add reads the register the add two instructions earlier wrote, so one
+// s_nop covers the two wait states the hardware wants between a VALU write and a DPP read (9 issue slots per scan
+// instead of the 18 of v_mov_dpp + v_add + s_nop the compiler emits for __builtin_amdgcn_update_dpp + add)
+__device__ __forceinline__ void wave_incl_scan2(uint32_t& a, uint32_t& b) {
+  asm volatile(
+      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_u32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "s_nop 0\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_u32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "s_nop 0\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_u32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "s_nop 0\n"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "v_add_u32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+      "s_nop 0\n"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "v_add_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "s_nop 0\n"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "v_add_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void copy_rows_wide(const uint8_t* __restrict__ in_data, uint8_t* __restrict__ out_base,
                                                int rs, int rl, int rd, int cnt, int lane);
@@ -1171,6 +1187,20 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         run += __popcll(m);
       }
     }
+    // Utf8 columns: the offsets of the first step are requested before the fixed-width copies, whose loads they join
+    constexpr int CH = 4;                                   // 64-row groups per step (8 spill at the 128-VGPR budget of the 1024-thread tile: 3.0 ms vs 2.2 ms)
+    uint32_t on[CH], nn[CH];
+    auto load_offsets = [&](int u, int j0) __attribute__((always_inline)) {
+      const int32_t* offs = p.utf8[u].in_offsets + w0;
+      const auto rs = wave_rows_rsrc(p.utf8[u].in_offsets, w0, 4, nact + 1);
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj) {
+        const uint32_t e = (uint32_t)((j0 + jj) * 64 + lane);
+        if (nact == 64 * R) { on[jj] = (uint32_t)offs[e]; nn[jj] = (uint32_t)offs[e + 1]; }
+        else { on[jj] = buf_load<uint32_t>(rs, (int)e); nn[jj] = buf_load<uint32_t>(rs, (int)e + 1); }
+      }
+    };
+    if constexpr (NU > 0) { if (p.n_utf8 > 0) load_offsets(0, 0); }
     const int ncopy = p.n_out - p.n_stash;   // the stashed columns are outs[ncopy .. n_out)
     auto copy_columns = [&](auto full_tag) {
       constexpr bool FULL = decltype(full_tag)::value;
@@ -1274,74 +1304,108 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         uint32_t boff = s_ubase[u];                         // first output byte of this wave's rows
         for (int w = 0; w < wv; ++w) boff += s_wave_bytes[buf][u][w];
         boff = __builtin_amdgcn_readfirstlane(boff);
-        const int32_t* offs = uf.in_offsets + w0;
         int32_t* oo = uf.out_offsets + off0;
-        const auto rs = wave_rows_rsrc(uf.in_offsets, w0, 4, nact + 1);
-        const bool complete = nact == 64 * R;
         unsigned run = 0;
+        // CH groups of 64 rows per step.  The offsets of the next step are requested right behind the data loads of the
+        // current one, so one memory latency per step is exposed (each step's data) instead of two; the stores of the
+        // new offsets are issued after those loads, so waiting for the data does not wait for them.  Everything
+        // wave-uniform (byte bases, group counts, ballots) lives in SGPRs.
+        if (u > 0) load_offsets(u, 0);
 #pragma unroll 1
-        for (int j0 = 0; j0 < R; j0 += 4) {                 // four 64-row groups at a time: 8 offset loads, then up to 16 data loads per lane in flight
-          int32_t src[4]; uint32_t len[4], dpos[4], gbase[4], gcnt[4];
+        for (int j0 = 0; j0 < R; j0 += CH) {
+          uint32_t src[CH], len[CH], dpos[CH], gbase[CH], gcnt[CH], grow[CH];   // (32-bit lane offsets off uniform bases)
           uint32_t longm = 0;                               // bit jj: the group's rows average > 24 bytes -> copy_rows_wide
+          uint32_t lor = 0;                                 // OR of the lengths this lane copies itself (>= their maximum)
+          uint32_t incl[CH];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int e = (j0 + jj) * 64 + lane;
-            uint32_t o, n;
-            if (complete) { o = (uint32_t)offs[e]; n = (uint32_t)offs[e + 1]; }
-            else { o = buf_load<uint32_t>(rs, e); n = buf_load<uint32_t>(rs, e + 1); }
-            src[jj] = (int32_t)o; len[jj] = n - o;
+          for (int jj = 0; jj < CH; ++jj) {
+            src[jj] = on[jj];
+            len[jj] = ((selv >> (j0 + jj)) & 1) ? nn[jj] - on[jj] : 0u;
+            incl[jj] = len[jj];
           }
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
+          for (int jj = 0; jj < CH; jj += 2) wave_incl_scan2(incl[jj], incl[jj + 1]);
+#pragma unroll
+          for (int jj = 0; jj < CH; ++jj) {
             const bool sel = (selv >> (j0 + jj)) & 1;
-            if (!sel) len[jj] = 0;
-            const uint32_t inc = wave_incl_scan(len[jj]);
+            const uint32_t inc = incl[jj];
             const uint32_t gb = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            const u64 m = __ballot(sel);
-            const uint32_t c = (uint32_t)__popcll(m);
+            const uint32_t c = (uint32_t)__popcll(__ballot(sel));
             dpos[jj] = boff + inc - len[jj];
-            if (sel) oo[run + lane_rank(m)] = (int32_t)dpos[jj];
-            if (gb > c * 24u) longm |= 1u << jj;
-            gbase[jj] = boff; gcnt[jj] = c;
+            if (gb > c * 24u) longm |= 1u << jj; else lor |= len[jj];
+            gbase[jj] = boff; gcnt[jj] = c; grow[jj] = run;
             boff += gb; run += c;
           }
-          uint32_t w4[4][4];
+          const bool more = __ballot(lor > 8u) != 0;                         // some row has bytes 8..15 to copy
+          const bool tails = __ballot((lor & 3u) != 0 || lor > 16u) != 0;    // some row is longer than 16 bytes or has 1-3 odd bytes
+          // bytes 0..7 of every row this lane copies: one 8-byte access where the row has them (the address unit's cost
+          // is per lane and instruction, not per byte), else one 4-byte access
+          uint32_t w4[CH][2];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
+          for (int jj = 0; jj < CH; ++jj) {
             const uint8_t* sp = uf.in_data + src[jj];
-            const bool shortg = !((longm >> jj) & 1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              w4[jj][q] = 0;
-              if (shortg && (uint32_t)(4 * q + 4) <= len[jj]) __builtin_memcpy(&w4[jj][q], sp + 4 * q, 4);
+            w4[jj][0] = 0; w4[jj][1] = 0;
+            if (!((longm >> jj) & 1)) {
+              if (len[jj] >= 8u) __builtin_memcpy(&w4[jj][0], sp, 8);
+              else if (len[jj] >= 4u) __builtin_memcpy(&w4[jj][0], sp, 4);
             }
           }
+          if (j0 + CH < R) load_offsets(u, j0 + CH);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
+          for (int jj = 0; jj < CH; ++jj) {
+            const bool sel = (selv >> (j0 + jj)) & 1;
+            const u64 m = __ballot(sel);
+            if (sel) oo[grow[jj] + lane_rank(m)] = (int32_t)dpos[jj];
+          }
+#pragma unroll
+          for (int jj = 0; jj < CH; ++jj) {
             if ((longm >> jj) & 1) continue;
-            const uint8_t* sp = uf.in_data + src[jj];
             uint8_t* dp = uf.out_data + dpos[jj];
-            const int l = (int)len[jj];
+            if (len[jj] >= 8u) __builtin_memcpy(dp, &w4[jj][0], 8);
+            else if (len[jj] >= 4u) __builtin_memcpy(dp, &w4[jj][0], 4);
+          }
+          if (more) {   // bytes 8..15, a second round through the same registers
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (4 * q + 4 <= l) __builtin_memcpy(dp + 4 * q, &w4[jj][q], 4);
-            int b = l < 16 ? (l & ~3) : 16;
-            for (; b + 4 <= l; b += 4) { uint32_t w; __builtin_memcpy(&w, sp + b, 4); __builtin_memcpy(dp + b, &w, 4); }
-            for (; b < l; ++b) dp[b] = sp[b];
+            for (int jj = 0; jj < CH; ++jj) {
+              const uint8_t* sp = uf.in_data + src[jj];
+              w4[jj][0] = 0; w4[jj][1] = 0;
+              if (!((longm >> jj) & 1)) {
+                if (len[jj] >= 16u) __builtin_memcpy(&w4[jj][0], sp + 8, 8);
+                else if (len[jj] >= 12u) __builtin_memcpy(&w4[jj][0], sp + 8, 4);
+              }
+            }
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+              if ((longm >> jj) & 1) continue;
+              uint8_t* dp = uf.out_data + dpos[jj];
+              if (len[jj] >= 16u) __builtin_memcpy(dp + 8, &w4[jj][0], 8);
+              else if (len[jj] >= 12u) __builtin_memcpy(dp + 8, &w4[jj][0], 4);
+            }
+          }
+          if (tails) {
+#pragma unroll
+            for (int jj = 0; jj < CH; ++jj) {
+              if ((longm >> jj) & 1) continue;
+              const uint8_t* sp = uf.in_data + src[jj];
+              uint8_t* dp = uf.out_data + dpos[jj];
+              const int l = (int)len[jj];
+              int b = l < 16 ? (l & ~3) : 16;
+              for (; b + 4 <= l; b += 4) { uint32_t w; __builtin_memcpy(&w, sp + b, 4); __builtin_memcpy(dp + b, &w, 4); }
+              for (; b < l; ++b) dp[b] = sp[b];
+            }
           }
           if (longm) {
 #pragma unroll 1
-            for (int jj = 0; jj < 4; ++jj) {
+            for (int jj = 0; jj < CH; ++jj) {
               if (!((longm >> jj) & 1)) continue;
               const bool sel = (selv >> (j0 + jj)) & 1;
               const u64 m = __ballot(sel);
               // (src, len, dst) of the selected rows in rank order: lane k serves the row of rank k
               const unsigned dl = sel ? lane_rank(m) : 63u - lane_rank(~m);
-              const int s0 = jj == 0 ? src[0] : jj == 1 ? src[1] : jj == 2 ? src[2] : src[3];
-              const uint32_t l0 = jj == 0 ? len[0] : jj == 1 ? len[1] : jj == 2 ? len[2] : len[3];
-              const uint32_t d0 = jj == 0 ? dpos[0] : jj == 1 ? dpos[1] : jj == 2 ? dpos[2] : dpos[3];
-              const uint32_t g0 = jj == 0 ? gbase[0] : jj == 1 ? gbase[1] : jj == 2 ? gbase[2] : gbase[3];
-              const uint32_t c0 = jj == 0 ? gcnt[0] : jj == 1 ? gcnt[1] : jj == 2 ? gcnt[2] : gcnt[3];
-              const int prs = __builtin_amdgcn_ds_permute((int)(dl << 2), s0);
+              uint32_t s0 = src[0], l0 = len[0], d0 = dpos[0], g0 = gbase[0], c0 = gcnt[0];
+#pragma unroll
+              for (int k = 1; k < CH; ++k) if (jj == k) { s0 = src[k]; l0 = len[k]; d0 = dpos[k]; g0 = gbase[k]; c0 = gcnt[k]; }
+              const int prs = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)s0);
               const int prl = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)l0);
               const int prd = __builtin_amdgcn_ds_permute((int)(dl << 2), (int)(d0 - g0));
               copy_rows_wide(uf.in_data, uf.out_data + g0, prs, prl, prd, (int)c0, lane);
