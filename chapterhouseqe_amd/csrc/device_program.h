@@ -144,7 +144,7 @@ struct Utf8Fold {
   const int32_t* in_offsets;   // at row 0
   const uint8_t* in_data;
   int32_t* out_offsets;        // [rows_out + 1]
-  uint8_t* out_data;
+  uint8_t* out_data;           // null: only the new offsets are written here; utf8_copy_kernel, launched right behind, moves the bytes (long strings)
   u64* status;                 // per tile, like FilterParams::status; zeroed before launch
   u64* total_bytes;            // out
 };

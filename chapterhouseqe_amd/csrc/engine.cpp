@@ -810,7 +810,9 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   // Utf8 columns of short strings are filtered inside the main kernel (device_program.h: Utf8Fold).  Their output
   // capacity is the input byte span: known when the library built the column itself (staged, joined, decoded), one
   // 8-byte read-back otherwise.
-  std::vector<int> fold_cols; std::vector<int64_t> fold_cap;
+  // Long strings (more than 24 bytes per row on average) get only their new offsets from the main kernel; the bytes are
+  // moved by utf8_copy_kernel (one wave per 64 rows), launched right behind it without a host round trip in between.
+  std::vector<int> fold_cols; std::vector<int64_t> fold_cap; std::vector<bool> fold_data;
   if (ctx.opt_fold_utf8 && tile_kind != 2 && !utf8_cols.empty() && mask_len == nrows) {
     const size_t ncand = std::min<size_t>(MAX_FOLD_UTF8, utf8_cols.size());
     std::vector<int64_t> cap(ncand, -1);
@@ -830,14 +832,15 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     }
     std::vector<int> rest;
     for (size_t k = 0; k < utf8_cols.size(); ++k) {
-      if (k < ncand && cap[k] <= mask_len * 24) { fold_cols.push_back(utf8_cols[k]); fold_cap.push_back(cap[k]); }
+      if (k < ncand) { fold_cols.push_back(utf8_cols[k]); fold_cap.push_back(cap[k]); fold_data.push_back(cap[k] <= mask_len * 24); }
       else rest.push_back(utf8_cols[k]);
     }
     utf8_cols.swap(rest);
   }
   std::vector<BufferPtr> fold_status;
+  const bool fold_long = std::find(fold_data.begin(), fold_data.end(), false) != fold_data.end();
   const bool need_followup = !bool_cols.empty() || !utf8_cols.empty() || !nullable_cols.empty() || (int)fixed_cols.size() > MAX_OUT ||
-                             (split && !split->starts.empty());
+                             (split && !split->starts.empty()) || fold_long;
   const int64_t ngroups = (mask_len + 63) / 64;
   BufferPtr sel_mask, grp_base;
   if (need_followup) {
@@ -896,7 +899,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
         fold_status.push_back(st);
         Utf8Fold& f = p.utf8[u];
         f.in_offsets = (const int32_t*)c.values0(); f.in_data = c.data;
-        f.out_offsets = (int32_t*)offb->ptr; f.out_data = (uint8_t*)db->ptr;
+        f.out_offsets = (int32_t*)offb->ptr; f.out_data = fold_data[u] ? (uint8_t*)db->ptr : nullptr;
         f.status = (u64*)st->ptr; f.total_bytes = &ds->fold_bytes[u];
         o.values = (const uint8_t*)offb->ptr; o.owned.push_back(offb);
         o.data = (const uint8_t*)db->ptr; o.owned.push_back(db);
@@ -928,6 +931,17 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
     }
     if (ctx.opt_time_kernels && first) check_hip(hipEventRecord(ctx.ev1, ctx.stream), "hipEventRecord");
     ++ctx.stats.launches;
+    if (first) {
+      for (size_t u = 0; u < fold_cols.size(); ++u) {
+        if (fold_data[u]) continue;
+        Utf8Params up{};
+        up.nrows = mask_len; up.sel_mask = (const u64*)sel_mask->ptr; up.grp_base = (const u64*)grp_base->ptr;
+        up.in_offsets = p.utf8[u].in_offsets; up.in_data = p.utf8[u].in_data;
+        up.out_offsets = p.utf8[u].out_offsets; up.out_data = (uint8_t*)out.cols[fold_cols[u]].data;
+        check_hip(launch_utf8_copy(up, (int)std::min<int64_t>((ngroups + 3) / 4, (int64_t)ctx.num_cus * 16), ctx.stream), "launch utf8_copy_kernel");
+        ++ctx.stats.launches;
+      }
+    }
     first = false;
   } while (next_fixed < fixed_cols.size());
 

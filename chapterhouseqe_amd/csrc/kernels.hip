@@ -1305,6 +1305,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
         for (int w = 0; w < wv; ++w) boff += s_wave_bytes[buf][u][w];
         boff = __builtin_amdgcn_readfirstlane(boff);
         int32_t* oo = uf.out_offsets + off0;
+        const bool copy = uf.out_data != nullptr;           // null: new offsets only, utf8_copy_kernel moves the (long) strings
         unsigned run = 0;
         // CH groups of 64 rows per step.  The offsets of the next step are requested right behind the data loads of the
         // current one, so one memory latency per step is exposed (each step's data) instead of two; the stores of the
@@ -1336,8 +1337,9 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
             gbase[jj] = boff; gcnt[jj] = c; grow[jj] = run;
             boff += gb; run += c;
           }
-          const bool more = __ballot(lor > 8u) != 0;                         // some row has bytes 8..15 to copy
-          const bool tails = __ballot((lor & 3u) != 0 || lor > 16u) != 0;    // some row is longer than 16 bytes or has 1-3 odd bytes
+          const bool more = copy && __ballot(lor > 8u) != 0;                         // some row has bytes 8..15 to copy
+          const bool tails = copy && __ballot((lor & 3u) != 0 || lor > 16u) != 0;    // some row is longer than 16 bytes or has 1-3 odd bytes
+          if (!copy) longm = 0;
           // bytes 0..7 of every row this lane copies: one 8-byte access where the row has them (the address unit's cost
           // is per lane and instruction, not per byte), else one 4-byte access
           uint32_t w4[CH][2];
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           for (int jj = 0; jj < CH; ++jj) {
             const uint8_t* sp = uf.in_data + src[jj];
             w4[jj][0] = 0; w4[jj][1] = 0;
-            if (!((longm >> jj) & 1)) {
+            if (copy && !((longm >> jj) & 1)) {
               if (len[jj] >= 8u) __builtin_memcpy(&w4[jj][0], sp, 8);
               else if (len[jj] >= 4u) __builtin_memcpy(&w4[jj][0], sp, 4);
             }
@@ -1359,7 +1361,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           }
 #pragma unroll
           for (int jj = 0; jj < CH; ++jj) {
-            if ((longm >> jj) & 1) continue;
+            if (!copy || ((longm >> jj) & 1)) continue;
             uint8_t* dp = uf.out_data + dpos[jj];
             if (len[jj] >= 8u) __builtin_memcpy(dp, &w4[jj][0], 8);
             else if (len[jj] >= 4u) __builtin_memcpy(dp, &w4[jj][0], 4);

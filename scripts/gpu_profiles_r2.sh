@@ -30,7 +30,7 @@ json.dump(out, open("$OUT/bench_pmc_hbm.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 # 2. config 3
-C3='python3 bench_configs.py --only config3 --no-select --steps 3'
+C3='python3 bench_configs.py --only compound --no-select --steps 3'
 timeout -k 10 280 rocprofv3 --kernel-trace -d $OUT/c3_trace -o r -- $C3 > $OUT/c3_trace.log 2>&1 || echo "c3 trace failed"
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/c3_fetch -o r -- $C3 > $OUT/c3_fetch.log 2>&1 || echo "c3 fetch failed"
 timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/c3_write -o r -- $C3 > $OUT/c3_write.log 2>&1 || echo "c3 write failed"
@@ -47,7 +47,7 @@ calls = f[name]["calls"]; big = calls - 1
 fetch = f[name]["counters"]["FETCH_SIZE"] * calls / big; write = w[next(iter(w))]["counters"]["WRITE_SIZE"] * calls / big
 out = {"kernel": name, "kernel_source_sha256": "$HASH", "dispatches_per_pass": calls, "note": "per-launch figures = pass total / %d full-size launches (the extra dispatch is the 2 M-row validation prefix)" % big,
        "fetch_bytes_corrected": fetch * 1024 * 2, "write_bytes": write * 1024, "traffic_bytes": fetch * 2048 + write * 1024,
-       "algorithmic_bytes": 32.5e9, "kernel_avg_ms": k[next(iter(k))]["avg_ms"] * calls / big,
+       "algorithmic_bytes": 32.5e9, "kernel_median_ms": k[next(iter(k))]["median_ms"], "kernel_durations_ms": k[next(iter(k))].get("durations_ms"),
        "sq_per_launch": {c: v * calls / big for c, v in q[next(iter(q))]["counters"].items()}, "command": "$C3"}
 json.dump(out, open("$OUT/config3_pmc.json", "w"), indent=1)
 print(json.dumps(out))
@@ -61,7 +61,7 @@ for c in config5 "config4 wide"; do
   timeout -k 10 280 rocprofv3 --kernel-trace -d $OUT/${n}_trace -o r -- python3 bench_configs.py --only "$c" --steps 3 > $OUT/${n}_trace.log 2>&1 || echo "$n trace failed"
   sumj $OUT/${n}_trace chq:: > $OUT/${n}_kernel_stats.json
   timeout -k 10 280 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY --kernel-trace -d $OUT/${n}_sq -o r -- python3 bench_configs.py --only "$c" --steps 3 > $OUT/${n}_sq.log 2>&1 || echo "$n sq failed"
-  sumj $OUT/${n}_sq utf8_ > $OUT/${n}_utf8_sq.json
+  sumj $OUT/${n}_sq chq:: > $OUT/${n}_sq.json
 done
 rm -rf $OUT/*/r_results.db $OUT/*_trace $OUT/*_fetch $OUT/*_write $OUT/*_sq 2>/dev/null
 ls -la $OUT

@@ -24,6 +24,11 @@ def summarise(path, want=None):
             k = out.setdefault(name, {"calls": 0, "avg_ms": None, "counters": {}})
             k["calls"] = max(k["calls"], n)
             k["avg_ms"] = avg / 1e6
+            durs = sorted(d[0] / 1e6 for d in cur.execute("select duration from kernels where name = ?", (name,)).fetchall())
+            k["median_ms"] = durs[len(durs) // 2]
+            k["max_ms"] = durs[-1]
+            if len(durs) <= 16:      # (a bench_configs pass = a few full-size launches + one small validation launch)
+                k["durations_ms"] = [round(d, 6) for d in durs]
         try:
             rows = cur.execute("select kernel_name, counter_name, count(distinct dispatch_id), sum(value) from counters_collection "
                                "group by kernel_name, counter_name").fetchall()
