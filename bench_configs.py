@@ -308,6 +308,24 @@ def main():
             counts = chq.filter_records(grp, al, pred, ctx=ctx, wrap=False)
             t1 = time.perf_counter()
             if it: per_call.append((t1 - t0) * 1e3)
+        # the C call alone (what a Rust / C caller pays): outputs released afterwards, outside the timed region
+        import ctypes as C
+        from chapterhouseqe_amd import _lib as L
+        from chapterhouseqe_amd.record_utils import _Aliases, _expr_to_c
+        ce, cal = _expr_to_c(pred), _Aliases(al)
+        ccall = []
+        for it in range(3):
+            outs = (L.ArrowDeviceArray * nb)(); schemas = (L.ArrowSchema * nb)()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = L.lib().chq_filter_records(ctx.handle, nb, grp.ptrs, C.byref(grp.schema), cal.ptr, ce, L.ARROW_DEVICE_ROCM, outs, schemas)
+            t1 = time.perf_counter()
+            assert rc == 0
+            rel = C.CFUNCTYPE(None, C.c_void_p)
+            for i in range(nb):
+                rel(outs[i].array.release)(C.addressof(outs[i].array)); rel(schemas[i].release)(C.addressof(schemas[i]))
+            ccall.append((t1 - t0) * 1e3)
+        L.lib().chq_expr_free(ce)
         coalesced_ms = None
         if n * L8 <= (1 << 30):
             for it in range(args.steps + 1):
@@ -327,7 +345,8 @@ def main():
         alg = n * (4 + 4 + L8 + 4) + rows_out * (4 + 4 + L8 + 4)
         per_call.sort()
         r = {"case": name, "rows": n, "batches": nb, "rows_per_batch": rows_per_batch, "where": where, "rows_out": rows_out,
-             "group_call_ms": per_call[len(per_call) // 2], "coalesced_call_ms": coalesced_ms, "per_batch_loop_us_per_batch": loop_us,
+             "group_call_ms": per_call[len(per_call) // 2], "c_call_ms": min(ccall), "us_per_batch_c_call": min(ccall) * 1e3 / nb,
+             "coalesced_call_ms": coalesced_ms, "per_batch_loop_us_per_batch": loop_us,
              "us_per_batch_group_call": per_call[len(per_call) // 2] * 1e3 / nb, "alg_bytes": alg,
              "group_call_GBps": alg / (per_call[len(per_call) // 2] * 1e-3) / 1e9, "note": note}
         results.append(r)
