@@ -82,6 +82,8 @@ EXPORTED_SYMBOLS = [
     "chq_expr_nested", "chq_expr_unsupported", "chq_expr_free", "chq_filter_record", "chq_filter_records", "chq_filter_records_coalesced", "chq_plan_describe", "chq_project_record",
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
     "chq_record_copy_to_peer", "chq_record_to_ipc", "chq_record_from_ipc", "chq_ipc_describe",
+    "chq_parquet_open", "chq_parquet_close", "chq_parquet_num_row_groups", "chq_parquet_row_group_num_rows",
+    "chq_parquet_describe", "chq_parquet_read_row_group",
 ]
 
 
@@ -154,6 +156,12 @@ def lib():
         "chq_record_to_ipc": (ci, [vp, PDA, PS, ci, C.POINTER(IpcMessage)]),
         "chq_record_from_ipc": (ci, [vp, vp, i64, vp, i64, ci, ci, PDA, PS]),
         "chq_ipc_describe": (ci, [vp, i64, C.c_char_p, C.c_size_t]),
+        "chq_parquet_open": (ci, [vp, i64, C.POINTER(vp), C.c_char_p, C.c_size_t]),
+        "chq_parquet_close": (None, [vp]),
+        "chq_parquet_num_row_groups": (C.c_int32, [vp]),
+        "chq_parquet_row_group_num_rows": (i64, [vp, C.c_int32]),
+        "chq_parquet_describe": (ci, [vp, C.c_char_p, C.c_size_t]),
+        "chq_parquet_read_row_group": (ci, [vp, vp, C.c_int32, ci, PDA, PS]),
     }
     for name, (res, args) in sig.items():
         try:

@@ -6,6 +6,7 @@
 #include <thread>
 
 #include "engine.hpp"
+#include "parquet.hpp"
 
 using namespace chq;
 
@@ -439,6 +440,52 @@ chq_status chq_ipc_describe(const uint8_t* stream, int64_t stream_len, char* buf
   }
   if (buf && buf_len) { const size_t k = std::min(buf_len - 1, text.size()); memcpy(buf, text.data(), k); buf[k] = 0; }
   return st;
+}
+
+// ---- Parquet scan -------------------------------------------------------------------------------------------------------
+struct chq_parquet { chq::PqFile file; };
+
+chq_status chq_parquet_open(const uint8_t* file, int64_t file_len, chq_parquet** out, char* err, size_t err_len) {
+  if (!out) return CHQ_ERR_ARROW_INVALID_ARGUMENT;
+  *out = nullptr;
+  std::string text;
+  chq_status st = CHQ_OK;
+  try {
+    auto* h = new chq_parquet();
+    try { h->file = parquet_open(file, file_len); } catch (...) { delete h; throw; }
+    *out = h;
+  } catch (const ChqError& e) {
+    text = e.msg; st = (chq_status)e.code;
+  } catch (const std::exception& e) {
+    text = e.what(); st = CHQ_ERR_ARROW_INVALID_ARGUMENT;
+  }
+  if (err && err_len) { const size_t k = std::min(err_len - 1, text.size()); memcpy(err, text.data(), k); err[k] = 0; }
+  return st;
+}
+void chq_parquet_close(chq_parquet* pq) { delete pq; }
+int32_t chq_parquet_num_row_groups(const chq_parquet* pq) { return pq ? (int32_t)pq->file.row_groups.size() : 0; }
+int64_t chq_parquet_row_group_num_rows(const chq_parquet* pq, int32_t row_group) {
+  return pq && row_group >= 0 && row_group < (int32_t)pq->file.row_groups.size() ? pq->file.row_groups[row_group].num_rows : -1;
+}
+chq_status chq_parquet_describe(const chq_parquet* pq, char* buf, size_t buf_len) {
+  if (!pq) return CHQ_ERR_INVALID_HANDLE;
+  const std::string text = parquet_describe(pq->file);
+  if (buf && buf_len) { const size_t k = std::min(buf_len - 1, text.size()); memcpy(buf, text.data(), k); buf[k] = 0; }
+  return text.size() < buf_len ? CHQ_OK : CHQ_ERR_ARROW_INVALID_ARGUMENT;
+}
+chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32_t row_group, int out_device,
+                                      ArrowDeviceArray* out, ArrowSchema* out_schema) {
+  if (!ctx || !pq) return CHQ_ERR_INVALID_HANDLE;
+  mark_released(out, out_schema);
+  return guarded(ctx, [&] {
+    require(out, "output array"); require(out_schema, "output schema");
+    if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch res = parquet_read_row_group(ctx->c, pq->file, row_group);
+    if (out_device == ARROW_DEVICE_CPU) res = to_host(ctx->c, res);
+    export_batch(std::move(res), out_device, out, out_schema);
+  });
 }
 
 chq_status chq_record_to_host(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, ArrowDeviceArray* out,

@@ -50,6 +50,7 @@ struct PqColumnChunk {
   int64_t num_values = 0;
   int64_t total_compressed_size = 0;
   int64_t data_page_offset = 0, dictionary_page_offset = -1;
+  int64_t stat_null_count = -1;   // from the chunk's Statistics, -1 = not recorded
   std::vector<int> encodings;
   std::vector<PqPage> pages;    // in file order, dictionary page (if any) first
   int64_t first_byte() const { return dictionary_page_offset > 0 && dictionary_page_offset < data_page_offset ? dictionary_page_offset : data_page_offset; }
@@ -73,7 +74,12 @@ struct PqFile {
 // NOT_SUPPORTED for nested schemas).
 PqFile parquet_open(const uint8_t* data, int64_t size);
 // "rows R row_groups G created_by ..." / "column <name> <physical> <required|optional> [utf8]" /
-// "rg <i> rows <n>" / "chunk <col> values <n> codec <c> pages <p>" / "page <type> values <n> enc <e> bytes <b>" lines
+// "rg <i> rows <n>" / "chunk <col> values <n> codec <c> pages <p>" / "page <type> values <n> enc <e> bytes <b> header <h>" lines
 std::string parquet_describe(const PqFile& f);
+
+struct Context;
+struct Batch;
+// One row group decoded into a device-resident batch (parquet_scan.cpp + parquet.hip).
+Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group);
 
 }  // namespace chq

@@ -1,0 +1,71 @@
+// parquet_device.h -- structs shared by parquet_scan.cpp (host) and parquet.hip (kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace chq {
+
+enum : uint32_t { PQ_ERR_LEVELS = 1, PQ_ERR_VALUES = 2 };   // *err after a decode: which part of some page was malformed
+
+// One data page of a column chunk.  Offsets are relative to the chunk buffer (the chunk as it lies in the file).
+struct PqPageDesc {
+  uint32_t levels_at;    // definition levels (RLE / bit-packed hybrid, bit width 1), behind their length prefix
+  uint32_t levels_len;   // 0: none (required column, or statistics say there are no nulls)
+  uint32_t values_at;
+  uint32_t values_len;
+  uint32_t num_rows;     // values of the page including nulls (flat schema: = rows)
+  uint32_t pad;
+  int64_t first_row;     // of the page inside the row group
+};
+
+struct PqDecodeParams {
+  const uint8_t* chunk;
+  const PqPageDesc* pages;
+  int32_t n_pages;
+  int32_t width;              // bytes per value (fixed-width types)
+  const int32_t* page_list;   // the pages a values kernel serves (indices into `pages`)
+  uint32_t* nonnull;          // [n_pages] non-null values per page (written by the levels kernel, or uploaded)
+  uint32_t* value_base;       // [n_pages] index of the page's first value among the chunk's non-null values
+  uint32_t* total_values;     // out: non-null values of the chunk
+  uint8_t* valid8;            // [rows] one byte per row
+  int32_t* row_val;           // [rows] value index, -1 = null
+  uint8_t* dense;             // fixed-width: [values] decoded values (BOOLEAN: one byte each)
+  uint32_t* vsrc;             // BYTE_ARRAY: [values] position of the bytes in the chunk buffer
+  uint32_t* vlen;             //             [values] length
+  uint32_t dict_at, dict_len, dict_count;   // dictionary page payload
+  uint32_t walk_dictionary;   // pq_ba_walk_kernel: walk the dictionary page instead of data pages
+  uint32_t* dict_src;         // BYTE_ARRAY dictionary: [dict_count] position / length of every entry
+  uint32_t* dict_len_out;
+  uint32_t* err;
+};
+
+struct PqRowParams {
+  int64_t n_rows;
+  const int32_t* row_val;     // null: row r holds value r (no nulls)
+  const uint8_t* dense;
+  const uint32_t* vsrc;
+  const uint32_t* vlen;
+  const uint8_t* chunk;
+  void* out;                  // gather: values; pack_bits: bitmap words; rowlen: int32 offsets [n_rows + 1]
+  const void* offsets;        // utf8 copy: the finished offsets
+  uint8_t* data_out;
+  unsigned long long* block_sums;   // [n_blocks]
+  int64_t n_blocks;
+  unsigned long long* total_bytes;
+};
+
+hipError_t pq_launch_levels(const PqDecodeParams& p, hipStream_t s);
+hipError_t pq_launch_page_scan(const PqDecodeParams& p, hipStream_t s);
+hipError_t pq_launch_rowval(const PqDecodeParams& p, hipStream_t s);
+hipError_t pq_launch_plain_copy(const PqDecodeParams& p, int n_list, hipStream_t s);
+hipError_t pq_launch_dict_fixed(const PqDecodeParams& p, int n_list, hipStream_t s);
+hipError_t pq_launch_bool(const PqDecodeParams& p, int n_list, hipStream_t s);
+hipError_t pq_launch_ba_walk(const PqDecodeParams& p, int n_list, hipStream_t s);
+hipError_t pq_launch_dict_ba(const PqDecodeParams& p, int n_list, hipStream_t s);
+hipError_t pq_launch_gather_fixed(const PqRowParams& p, int width, int grid, hipStream_t s);
+hipError_t pq_launch_pack_bits(const PqRowParams& p, int grid, hipStream_t s);
+hipError_t pq_launch_rowlen(const PqRowParams& p, hipStream_t s);
+hipError_t pq_launch_utf8_copy(const PqRowParams& p, int grid, hipStream_t s);
+constexpr int PQ_SCAN_ROWS_HOST = 4096;   // = PQ_SCAN_ROWS of parquet.hip
+
+}  // namespace chq

@@ -119,6 +119,10 @@ PqColumnChunk read_column_chunk(Thrift& t) {
         case 7: c.total_compressed_size = t.zigzag(); break;
         case 9: c.data_page_offset = t.zigzag(); break;
         case 11: c.dictionary_page_offset = t.zigzag(); break;
+        case 12: {   // Statistics: only null_count (field 3) is used -- "no nulls" lets the scan skip the definition levels
+          int sid, sty, slast = 0;
+          while (t.field(sid, sty, slast)) { if (sid == 3) c.stat_null_count = t.zigzag(); else t.skip(sty); }
+        } break;
         default: t.skip(mty);
       }
     }
@@ -257,7 +261,8 @@ std::string parquet_describe(const PqFile& f) {
       const PqColumnChunk& c = rg.columns[k];
       o += "chunk " + std::to_string(k) + " values " + std::to_string(c.num_values) + " codec " + std::to_string(c.codec) + " pages " + std::to_string(c.pages.size()) + "\n";
       for (const PqPage& pg : c.pages)
-        o += "page " + std::to_string(pg.type) + " values " + std::to_string(pg.num_values) + " enc " + std::to_string(pg.encoding) + " bytes " + std::to_string(pg.compressed_size) + "\n";
+        o += "page " + std::to_string(pg.type) + " values " + std::to_string(pg.num_values) + " enc " + std::to_string(pg.encoding) + " bytes " + std::to_string(pg.compressed_size) +
+             " header " + std::to_string(pg.payload_at - pg.header_at) + "\n";
     }
   }
   return o;

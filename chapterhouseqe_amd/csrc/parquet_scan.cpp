@@ -1,0 +1,262 @@
+// parquet_scan.cpp -- orchestration of the GPU page decode (parquet.hip) for one row group.  See parquet.hpp for scope.
+#include <cstring>
+
+#include "engine.hpp"
+#include "parquet.hpp"
+#include "parquet_device.h"
+
+namespace chq {
+namespace {
+
+[[noreturn]] void unsupported(const std::string& what) { throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: " + what}; }
+[[noreturn]] void malformed(const std::string& what) { throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: " + what}; }
+
+template <typename T>
+BufferPtr upload(Context& ctx, const std::vector<T>& v) {
+  auto b = make_device_buffer(v.size() * sizeof(T) + 16, ctx.device);
+  if (!v.empty()) check_hip(hipMemcpyAsync(b->ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx.stream), "upload page table");
+  return b;
+}
+
+struct Scalars {   // per column, on the device and read back once per phase
+  uint32_t err, total_values;
+  unsigned long long total_bytes;
+};
+
+struct ColumnWork {
+  const PqColumnSchema* schema = nullptr;
+  const PqColumnChunk* chunk = nullptr;
+  const char* format = nullptr;
+  int width = 0;              // fixed-width types
+  bool byte_array = false, boolean = false;
+  bool has_levels = false;    // definition levels are decoded (optional column whose statistics do not rule nulls out)
+  int64_t rows = 0;
+  BufferPtr chunkb, pages, nonnull, value_base, valid8, row_val, dense, vsrc, vlen, dict_src, dict_len, offsets, block_sums;
+  std::vector<BufferPtr> keep;   // page lists: alive until the stream has run
+  int64_t host_values = 0;    // non-null values when known on the host (no levels)
+};
+
+}  // namespace
+
+Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
+  if (row_group < 0 || row_group >= (int)f.row_groups.size()) malformed("row group " + std::to_string(row_group) + " of " + std::to_string(f.row_groups.size()));
+  const PqRowGroup& rg = f.row_groups[row_group];
+  const int64_t rows = rg.num_rows;
+  if (rows < 0 || rows >= (1ll << 31)) unsupported("row group of " + std::to_string(rows) + " rows");
+  const size_t nc = f.columns.size();
+  std::vector<ColumnWork> work(nc);
+  auto scal = make_device_buffer(sizeof(Scalars) * (nc + 1), ctx.device);
+  check_hip(hipMemsetAsync(scal->ptr, 0, sizeof(Scalars) * (nc + 1), ctx.stream), "memset");
+  Scalars* dscal = (Scalars*)scal->ptr;
+
+  // ---- phase A: everything up to the Utf8 offsets --------------------------------------------------------------------
+  for (size_t ci = 0; ci < nc; ++ci) {
+    const PqColumnSchema& cs = f.columns[ci];
+    const PqColumnChunk& cc = rg.columns[ci];
+    ColumnWork& w = work[ci];
+    w.schema = &cs; w.chunk = &cc; w.rows = rows;
+    if (cs.repetition > 1) unsupported("repeated column '" + cs.name + "'");
+    if (cs.logical_other) unsupported("logical type of column '" + cs.name + "'");
+    if (cc.codec != 0) unsupported("compression codec " + std::to_string(cc.codec) + " (column '" + cs.name + "'); only UNCOMPRESSED, which is what the reference's writers produce");
+    if (cc.num_values != rows) malformed("column '" + cs.name + "' holds " + std::to_string(cc.num_values) + " values for " + std::to_string(rows) + " rows");
+    const bool is_string = cs.logical_string || cs.converted_type == 0;
+    if (cs.converted_type > 0 && !((cs.converted_type == 17 && cs.type == PQ_INT32) || (cs.converted_type == 18 && cs.type == PQ_INT64)))
+      unsupported("converted type " + std::to_string(cs.converted_type) + " of column '" + cs.name + "'");
+    switch (cs.type) {
+      case PQ_BOOLEAN: w.format = "b"; w.boolean = true; w.width = 1; break;
+      case PQ_INT32: w.format = "i"; w.width = 4; break;
+      case PQ_INT64: w.format = "l"; w.width = 8; break;
+      case PQ_FLOAT: w.format = "f"; w.width = 4; break;
+      case PQ_DOUBLE: w.format = "g"; w.width = 8; break;
+      case PQ_BYTE_ARRAY:
+        if (!is_string) unsupported("BYTE_ARRAY column '" + cs.name + "' without the String annotation");
+        w.format = "u"; w.byte_array = true; break;
+      default: unsupported("physical type " + std::to_string(cs.type) + " of column '" + cs.name + "'");
+    }
+    const int64_t first = cc.first_byte(), csize = cc.total_compressed_size;
+    if (csize >= (1ll << 32) - 64) unsupported("column chunk of " + std::to_string(csize) + " bytes");
+    w.chunkb = make_device_buffer((size_t)csize + 64, ctx.device);
+    check_hip(hipMemcpyAsync(w.chunkb->ptr, f.data + first, (size_t)csize, hipMemcpyHostToDevice, ctx.stream), "upload column chunk");
+    check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + csize, 0, 64, ctx.stream), "memset");
+
+    const bool optional = cs.repetition == 1;
+    w.has_levels = optional && cc.stat_null_count != 0;
+    std::vector<PqPageDesc> descs;
+    std::vector<int32_t> plain_list, dict_list;
+    std::vector<uint32_t> h_nonnull, h_base;
+    uint32_t dict_at = 0, dict_len = 0, dict_count = 0;
+    bool have_dict = false;
+    int64_t row_at = 0;
+    for (const PqPage& pg : cc.pages) {
+      if (pg.compressed_size != pg.uncompressed_size) malformed("uncompressed page whose sizes differ");
+      const int64_t rel = pg.payload_at - first;
+      if (rel < 0 || rel + pg.compressed_size > csize) malformed("page outside its column chunk");
+      if (pg.type == PQ_DICTIONARY_PAGE) {
+        if (pg.encoding != PQ_PLAIN && pg.encoding != PQ_PLAIN_DICTIONARY) unsupported("dictionary page encoding " + std::to_string(pg.encoding));
+        if (pg.num_values < 0 || pg.num_values >= (1ll << 31)) malformed("dictionary size");
+        dict_at = (uint32_t)rel; dict_len = (uint32_t)pg.compressed_size; dict_count = (uint32_t)pg.num_values; have_dict = true;
+        continue;
+      }
+      if (pg.type == PQ_INDEX_PAGE) continue;
+      if (pg.type != PQ_DATA_PAGE && pg.type != PQ_DATA_PAGE_V2) unsupported("page type " + std::to_string(pg.type));
+      PqPageDesc d{};
+      d.num_rows = (uint32_t)pg.num_values; d.first_row = row_at;
+      int64_t at = rel, left = pg.compressed_size;
+      if (pg.type == PQ_DATA_PAGE) {
+        if (optional) {   // [4-byte length][RLE hybrid levels]
+          if (pg.def_encoding != PQ_RLE) unsupported("definition level encoding " + std::to_string(pg.def_encoding));
+          if (left < 4) malformed("page too short for its definition levels");
+          uint32_t l; memcpy(&l, f.data + pg.payload_at, 4);
+          if ((int64_t)l + 4 > left) malformed("definition levels run past the page");
+          d.levels_at = (uint32_t)(at + 4); d.levels_len = l;
+          at += 4 + l; left -= 4 + l;
+        }
+      } else {
+        if (pg.rep_bytes != 0) unsupported("repetition levels");
+        if (pg.def_bytes < 0 || pg.def_bytes > left) malformed("definition levels run past the page");
+        d.levels_at = (uint32_t)at; d.levels_len = (uint32_t)pg.def_bytes;
+        at += pg.def_bytes; left -= pg.def_bytes;
+        if (!optional && pg.def_bytes != 0) malformed("definition levels on a required column");
+      }
+      if (optional && w.has_levels && d.levels_len == 0 && d.num_rows > 0) malformed("optional column without definition levels");
+      if (!w.has_levels) d.levels_len = 0;
+      d.values_at = (uint32_t)at; d.values_len = (uint32_t)left;
+      const int page_index = (int)descs.size();
+      if (pg.encoding == PQ_PLAIN) plain_list.push_back(page_index);
+      else if (pg.encoding == PQ_RLE_DICTIONARY || pg.encoding == PQ_PLAIN_DICTIONARY) {
+        if (!have_dict) malformed("dictionary-encoded page without a dictionary page in front of it");
+        dict_list.push_back(page_index);
+      } else unsupported("encoding " + std::to_string(pg.encoding) + " (column '" + cs.name + "')");
+      h_nonnull.push_back(d.num_rows); h_base.push_back((uint32_t)row_at);
+      row_at += pg.num_values;
+      descs.push_back(d);
+    }
+    if (row_at != rows) malformed("pages of column '" + cs.name + "' hold " + std::to_string(row_at) + " rows, the row group has " + std::to_string(rows));
+    const int n_pages = (int)descs.size();
+    w.pages = upload(ctx, descs);
+    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, h_nonnull);
+    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, h_base);
+    w.host_values = rows;
+
+    PqDecodeParams p{};
+    p.chunk = (const uint8_t*)w.chunkb->ptr; p.pages = (const PqPageDesc*)w.pages->ptr; p.n_pages = n_pages; p.width = w.width;
+    p.nonnull = (uint32_t*)w.nonnull->ptr; p.value_base = (uint32_t*)w.value_base->ptr;
+    p.total_values = &dscal[ci].total_values; p.err = &dscal[ci].err;
+    p.dict_at = dict_at; p.dict_len = dict_len; p.dict_count = dict_count;
+    if (rows == 0 || n_pages == 0) continue;   // (an empty row group: phase B builds empty columns)
+    if (w.has_levels) {
+      w.valid8 = make_device_buffer((size_t)rows + 64, ctx.device);
+      w.row_val = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
+      p.valid8 = (uint8_t*)w.valid8->ptr; p.row_val = (int32_t*)w.row_val->ptr;
+      check_hip(pq_launch_levels(p, ctx.stream), "launch pq_levels_kernel");
+      check_hip(pq_launch_page_scan(p, ctx.stream), "launch pq_page_scan_kernel");
+      check_hip(pq_launch_rowval(p, ctx.stream), "launch pq_rowval_kernel");
+    }
+    // dense values: at most `rows` of them
+    auto plain_dev = upload(ctx, plain_list), dict_dev = upload(ctx, dict_list);
+    w.keep.push_back(plain_dev); w.keep.push_back(dict_dev);
+    if (w.byte_array) {
+      w.vsrc = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
+      w.vlen = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
+      p.vsrc = (uint32_t*)w.vsrc->ptr; p.vlen = (uint32_t*)w.vlen->ptr;
+      if (!dict_list.empty()) {
+        w.dict_src = make_device_buffer((size_t)dict_count * 4 + 64, ctx.device);
+        w.dict_len = make_device_buffer((size_t)dict_count * 4 + 64, ctx.device);
+        p.dict_src = (uint32_t*)w.dict_src->ptr; p.dict_len_out = (uint32_t*)w.dict_len->ptr;
+        if (dict_count > 0) { p.walk_dictionary = 1; check_hip(pq_launch_ba_walk(p, 1, ctx.stream), "launch pq_ba_walk_kernel (dictionary)"); p.walk_dictionary = 0; }
+        p.page_list = (const int32_t*)dict_dev->ptr;
+        check_hip(pq_launch_dict_ba(p, (int)dict_list.size(), ctx.stream), "launch pq_dict_ba_kernel");
+      }
+      if (!plain_list.empty()) {
+        p.page_list = (const int32_t*)plain_dev->ptr;
+        check_hip(pq_launch_ba_walk(p, (int)plain_list.size(), ctx.stream), "launch pq_ba_walk_kernel");
+      }
+      // offsets = exclusive scan of the row lengths
+      w.offsets = make_device_buffer((size_t)(rows + 2) * 4, ctx.device);
+      const int64_t n_blocks = (rows + PQ_SCAN_ROWS_HOST - 1) / PQ_SCAN_ROWS_HOST;
+      w.block_sums = make_device_buffer((size_t)n_blocks * 8 + 16, ctx.device);
+      PqRowParams r{};
+      r.n_rows = rows; r.row_val = w.has_levels ? (const int32_t*)w.row_val->ptr : nullptr;
+      r.vlen = (const uint32_t*)w.vlen->ptr; r.out = w.offsets->ptr;
+      r.block_sums = (unsigned long long*)w.block_sums->ptr; r.n_blocks = n_blocks; r.total_bytes = &dscal[ci].total_bytes;
+      check_hip(pq_launch_rowlen(r, ctx.stream), "launch pq_rowlen kernels");
+    } else {
+      if (dict_count > 0 && (uint64_t)dict_count * w.width > dict_len) malformed("dictionary page shorter than its entries");
+      w.dense = make_device_buffer((size_t)rows * w.width + 64, ctx.device);
+      p.dense = (uint8_t*)w.dense->ptr;
+      if (!plain_list.empty()) {
+        p.page_list = (const int32_t*)plain_dev->ptr;
+        if (w.boolean) check_hip(pq_launch_bool(p, (int)plain_list.size(), ctx.stream), "launch pq_bool_kernel");
+        else check_hip(pq_launch_plain_copy(p, (int)plain_list.size(), ctx.stream), "launch pq_plain_copy_kernel");
+      }
+      if (!dict_list.empty()) {
+        if (w.boolean) unsupported("dictionary-encoded BOOLEAN column");
+        p.page_list = (const int32_t*)dict_dev->ptr;
+        check_hip(pq_launch_dict_fixed(p, (int)dict_list.size(), ctx.stream), "launch pq_dict_fixed_kernel");
+      }
+    }
+  }
+  std::vector<Scalars> hs(nc + 1);
+  check_hip(hipMemcpyAsync(hs.data(), scal->ptr, sizeof(Scalars) * nc, hipMemcpyDeviceToHost, ctx.stream), "read back");
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+
+  // ---- phase B: per-row outputs ---------------------------------------------------------------------------------------
+  Batch out;
+  out.on_device = true; out.device_id = ctx.device; out.nrows = rows;
+  const int grid = ctx.num_cus * 8;
+  for (size_t ci = 0; ci < nc; ++ci) {
+    ColumnWork& w = work[ci];
+    if (hs[ci].err) malformed(std::string(hs[ci].err == PQ_ERR_LEVELS ? "definition levels" : "values") + " of column '" + w.schema->name + "' are malformed");
+    Column o;
+    o.name = w.schema->name; o.format = w.format; o.nullable = w.schema->repetition == 1; o.length = rows; o.offset = 0;
+    parse_arrow_format(w.format, &o.type, &o.width);
+    const int64_t nonnull = w.has_levels && rows > 0 ? (int64_t)hs[ci].total_values : rows;
+    o.null_count = rows - nonnull;
+    const int32_t* row_val = (w.has_levels && o.null_count > 0) ? (const int32_t*)w.row_val->ptr : nullptr;
+    if (rows == 0) {
+      auto vb = make_device_buffer(64, ctx.device);
+      check_hip(hipMemsetAsync(vb->ptr, 0, 64, ctx.stream), "memset");
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+      if (w.byte_array) { auto db = make_device_buffer(64, ctx.device); o.data = (const uint8_t*)db->ptr; o.owned.push_back(db); o.data_bytes = 0; }
+      out.cols.push_back(std::move(o));
+      continue;
+    }
+    if (o.null_count > 0) {   // validity bitmap from the one-byte-per-row levels
+      auto vb = make_device_buffer((size_t)((rows + 63) / 64) * 8 + 16, ctx.device);
+      PqRowParams r{};
+      r.n_rows = rows; r.dense = (const uint8_t*)w.valid8->ptr; r.out = vb->ptr;
+      check_hip(pq_launch_pack_bits(r, grid, ctx.stream), "launch pq_pack_bits_kernel");
+      o.validity = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    }
+    if (w.byte_array) {
+      const unsigned long long total = hs[ci].total_bytes;
+      if (total >= (1ull << 31)) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "offset overflow: column '" + o.name + "' of this row group holds " + std::to_string(total) + " bytes; Utf8 offsets are int32"};
+      auto db = make_device_buffer((size_t)total + 64, ctx.device);
+      PqRowParams r{};
+      r.n_rows = rows; r.row_val = row_val; r.vsrc = (const uint32_t*)w.vsrc->ptr; r.vlen = (const uint32_t*)w.vlen->ptr;
+      r.chunk = (const uint8_t*)w.chunkb->ptr; r.offsets = w.offsets->ptr; r.data_out = (uint8_t*)db->ptr;
+      check_hip(pq_launch_utf8_copy(r, grid, ctx.stream), "launch pq_utf8_copy_kernel");
+      o.values = (const uint8_t*)w.offsets->ptr; o.owned.push_back(w.offsets);
+      o.data = (const uint8_t*)db->ptr; o.owned.push_back(db); o.data_bytes = (int64_t)total;
+    } else if (w.boolean) {
+      auto vb = make_device_buffer((size_t)((rows + 63) / 64) * 8 + 16, ctx.device);
+      PqRowParams r{};
+      r.n_rows = rows; r.row_val = row_val; r.dense = (const uint8_t*)w.dense->ptr; r.out = vb->ptr;
+      check_hip(pq_launch_pack_bits(r, grid, ctx.stream), "launch pq_pack_bits_kernel");
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    } else if (row_val) {
+      auto vb = make_device_buffer((size_t)rows * w.width + 64, ctx.device);
+      PqRowParams r{};
+      r.n_rows = rows; r.row_val = row_val; r.dense = (const uint8_t*)w.dense->ptr; r.out = vb->ptr;
+      check_hip(pq_launch_gather_fixed(r, w.width, grid, ctx.stream), "launch pq_gather_fixed_kernel");
+      o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
+    } else {   // no nulls: the dense values ARE the column
+      o.values = (const uint8_t*)w.dense->ptr; o.owned.push_back(w.dense);
+    }
+    out.cols.push_back(std::move(o));
+  }
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the temporaries of `work` are released on return
+  return out;
+}
+
+}  // namespace chq

@@ -445,6 +445,67 @@ def ipc_describe(stream: bytes) -> str:
     return text
 
 
+class ParquetFile:
+    """A Parquet file whose pages are decoded on the GPU (`chq_parquet_*`) -- the device-side form
+    of what `read_files_task.rs:233-282` does with `ParquetRecordBatchStreamBuilder`.  `source`: a path or the file's
+    bytes; they stay referenced (the library borrows the memory) until `close()`."""
+
+    def __init__(self, source):
+        import numpy as np
+        if isinstance(source, (bytes, bytearray, memoryview)):
+            self._bytes = np.frombuffer(source, dtype=np.uint8)
+        else:
+            self._bytes = np.fromfile(source, dtype=np.uint8)
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = L.lib().chq_parquet_open(self._bytes.ctypes.data, self._bytes.size, C.byref(self._h), err, len(err))
+        if rc:
+            raise ChqError(rc, err.value.decode(errors="replace"))
+
+    @property
+    def num_row_groups(self) -> int:
+        return L.lib().chq_parquet_num_row_groups(self._h)
+
+    def row_group_num_rows(self, i: int) -> int:
+        return L.lib().chq_parquet_row_group_num_rows(self._h, i)
+
+    def describe(self) -> str:
+        """Host half only (no GPU): schema, row groups, column chunks and pages as text."""
+        buf = C.create_string_buffer(1 << 22)
+        rc = L.lib().chq_parquet_describe(self._h, buf, len(buf))
+        if rc:
+            raise ChqError(rc, "describe buffer too small")
+        return buf.value.decode(errors="replace")
+
+    def read_row_group(self, i: int, *, ctx: Optional[Context] = None, device_result: bool = True):
+        ctx = ctx or default_context()
+        out = _CBatch()
+        rc = L.lib().chq_parquet_read_row_group(ctx.handle, self._h, i, L.ARROW_DEVICE_ROCM if device_result else L.ARROW_DEVICE_CPU,
+                                                C.byref(out.array), C.byref(out.schema))
+        return _finish(ctx, rc, out, device_result)
+
+    def close(self) -> None:
+        if self._h:
+            L.lib().chq_parquet_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def scan_parquet(source, *, ctx: Optional[Context] = None, device_result: bool = True):
+    """Every row group of a Parquet file as one batch each, decoded on the GPU (generator)."""
+    f = ParquetFile(source)
+    try:
+        for i in range(f.num_row_groups):
+            yield f.read_row_group(i, ctx=ctx, device_result=device_result)
+    finally:
+        f.close()
+
+
 class RecordGroup:
     """A prepared argument block for `filter_records`: the C pointer array over a list of same-schema batches.
     Building it once lets a caller that re-filters the same batches (benchmarks) keep Python out of the call."""

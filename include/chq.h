@@ -264,6 +264,30 @@ chq_status chq_record_from_ipc(chq_ctx* ctx, const uint8_t* stream, int64_t stre
  * by the CPU test tier (the flatbuffer reader against pyarrow's writer) and for debugging. */
 chq_status chq_ipc_describe(const uint8_t* stream, int64_t stream_len, char* buf, size_t buf_len);
 
+/* ---- Parquet scan with the page decode on the GPU --------------------------------------------
+ * Replaces the decode the reference does with the `parquet` crate in front of the filter path
+ * (operators/table_func_tasks/read_files_task.rs:233-282: ParquetRecordBatchStreamBuilder::new(reader) ...
+ * with_batch_size(max_rows_per_batch)): the caller hands over the file's bytes (host memory, borrowed until
+ * chq_parquet_close), the library parses footer and page headers on the host, uploads each column chunk as it lies in the
+ * file and decodes the pages into Arrow buffers in HBM.  One call yields one ROW GROUP as one device-resident batch (the
+ * reference cuts 10 000-row batches; slices of the result are zero-copy, and the filter kernels prefer large batches).
+ * Scope: flat schemas; BOOLEAN, INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY annotated String; required / optional columns;
+ * PLAIN and RLE_DICTIONARY / PLAIN_DICTIONARY (also mixed inside a chunk: the writers' dictionary fallback); data pages
+ * V1 and V2; UNCOMPRESSED (what the reference's writers produce: create_sample_data.rs:222,
+ * materialize_files_task.rs:128-133).  Everything else: CHQ_ERR_NOT_SUPPORTED, the message names the feature. */
+typedef struct chq_parquet chq_parquet;
+/* Footer + page headers; no GPU, no context.  On failure *out is NULL and `err` (if given) receives the message. */
+chq_status chq_parquet_open(const uint8_t* file, int64_t file_len, chq_parquet** out, char* err, size_t err_len);
+void chq_parquet_close(chq_parquet* pq);
+int32_t chq_parquet_num_row_groups(const chq_parquet* pq);
+int64_t chq_parquet_row_group_num_rows(const chq_parquet* pq, int32_t row_group);
+/* "rows R row_groups G columns C" / "column <name> <physical> <required|optional> [utf8]" / "rg <i> rows <n>" /
+ * "chunk <col> values <n> codec <c> pages <p>" / "page <type> values <n> enc <e> bytes <b> header <h>" lines (CPU test tier) */
+chq_status chq_parquet_describe(const chq_parquet* pq, char* buf, size_t buf_len);
+/* Decode one row group.  `out_device`: ARROW_DEVICE_ROCM (stays in HBM) or ARROW_DEVICE_CPU (copied down). */
+chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32_t row_group, int out_device,
+                                      struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+
 /* Wrap caller-owned device (or host) buffers as a record batch without copying; the buffers must
  * outlive the returned structs, whose release callbacks free only the descriptors. `format` is an
  * Arrow C format string ("i","f","g","l","b","u", ...). */

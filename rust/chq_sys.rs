@@ -26,6 +26,10 @@ pub struct chq_ctx {
 pub struct chq_expr {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct chq_parquet {
+    _private: [u8; 0],
+}
 
 #[repr(C)]
 pub struct chq_select_item {
@@ -176,6 +180,17 @@ extern "C" {
         body_device_type: c_int, out_device: c_int, out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
     ) -> c_int;
     pub fn chq_ipc_describe(stream: *const u8, stream_len: i64, buf: *mut c_char, buf_len: usize) -> c_int;
+
+    // ---- Parquet scan, page decode on the GPU (read_files_task.rs:233-282) ----
+    pub fn chq_parquet_open(file: *const u8, file_len: i64, out: *mut *mut chq_parquet, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn chq_parquet_close(pq: *mut chq_parquet);
+    pub fn chq_parquet_num_row_groups(pq: *const chq_parquet) -> i32;
+    pub fn chq_parquet_row_group_num_rows(pq: *const chq_parquet, row_group: i32) -> i64;
+    pub fn chq_parquet_describe(pq: *const chq_parquet, buf: *mut c_char, buf_len: usize) -> c_int;
+    pub fn chq_parquet_read_row_group(
+        ctx: *mut chq_ctx, pq: *const chq_parquet, row_group: i32, out_device: c_int,
+        out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
     pub fn chq_wrap_columns(
         ctx: *mut chq_ctx, cols: *const chq_column_desc, n_cols: c_int, n_rows: i64, device_type: c_int,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,

@@ -1,0 +1,122 @@
+"""GPU: Parquet pages decoded by the kernels of csrc/parquet.hip against pyarrow's reader on the
+same bytes -- bit-exact values, validity, null counts, offsets and string bytes, over encodings (PLAIN, RLE_DICTIONARY, the
+writers' mid-chunk fallback from one to the other), data page versions, page sizes, nulls, row groups and edge cases."""
+import io
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+import chapterhouseqe_amd as chq
+from chapterhouseqe_amd.sqlparse import parse_expr
+from oracle import oracle as O
+from tests.parquet_cases import sample_table, write_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = chq.Context(0)
+    yield c
+    c.close()
+
+
+def check(raw: bytes, ctx, device_result=True):
+    exp = pq.ParquetFile(io.BytesIO(raw))
+    f = chq.ParquetFile(raw)
+    assert f.num_row_groups == exp.metadata.num_row_groups
+    for g in range(f.num_row_groups):
+        want = exp.read_row_group(g).combine_chunks()
+        got = f.read_row_group(g, ctx=ctx, device_result=device_result)
+        if device_result:
+            got = got.to_host()
+        assert got.num_rows == want.num_rows and got.schema.names == want.schema.names
+        for i, name in enumerate(want.schema.names):
+            w = want.column(i).chunk(0) if want.num_rows else pa.array([], type=want.schema.field(i).type)
+            x = got.column(i)
+            assert x.type == w.type, name
+            assert x.null_count == w.null_count, name
+            assert x.equals(w), f"{name}: row group {g}"
+    f.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(use_dictionary=False), dict(data_page_version="2.0"), dict(use_dictionary=False, data_page_version="2.0"),
+    dict(data_page_size=300), dict(data_page_size=300, use_dictionary=False), dict(row_group_size=1500, data_page_size=2000),
+    dict(dictionary_pagesize_limit=2048, data_page_size=1024), dict(write_statistics=False),
+])
+@pytest.mark.parametrize("nulls", [False, True])
+@pytest.mark.parametrize("strings", ["mixed", "unique", "few"])
+def test_row_groups_match_pyarrow(ctx, kw, nulls, strings):
+    for n in [1, 63, 64, 65, 1000, 4097, 20_000]:
+        check(write_bytes(sample_table(n, seed=n, nulls=nulls, strings=strings), **kw), ctx)
+
+
+def test_edge_cases(ctx):
+    # no rows at all; all-null columns; empty strings only; a string far longer than the walker's LDS window; one huge page
+    check(write_bytes(sample_table(0)), ctx)
+    n = 3000
+    t = pa.table({"allnull": pa.array([None] * n, type=pa.int32()), "nullstr": pa.array([None] * n, type=pa.utf8()),
+                  "empty": pa.array([""] * n), "bools": pa.array([True, False, None] * (n // 3))})
+    for kw in [dict(), dict(use_dictionary=False), dict(data_page_version="2.0", data_page_size=100)]:
+        check(write_bytes(t, **kw), ctx)
+    big = ["x" * 40_000, "", "y" * 17_000, "short", "z" * 70_000] * 7
+    for kw in [dict(), dict(use_dictionary=False), dict(use_dictionary=False, data_page_size=1 << 22)]:
+        check(write_bytes(pa.table({"s": pa.array(big), "k": pa.array(np.arange(len(big), dtype=np.int64))}), **kw), ctx)
+    rng = np.random.default_rng(5)
+    one_page = pa.table({"v": pa.array(rng.integers(0, 1000, 300_000).astype(np.int32)), "s": pa.array(["%05d" % v for v in rng.integers(0, 99999, 300_000)])})
+    for kw in [dict(data_page_size=1 << 26), dict(data_page_size=1 << 26, use_dictionary=False)]:
+        check(write_bytes(one_page, **kw), ctx)
+
+
+def test_host_result_and_required_columns(ctx):
+    n = 5000
+    rng = np.random.default_rng(9)
+    schema = pa.schema([pa.field("id", pa.int32(), nullable=False), pa.field("value1", pa.utf8(), nullable=False),
+                        pa.field("value2", pa.float32(), nullable=False)])
+    t = pa.table([pa.array(np.arange(n, dtype=np.int32)), pa.array(["%08x" % v for v in rng.integers(0, 2**32, n)]),
+                  pa.array((rng.random(n) * 100).astype(np.float32))], schema=schema)
+    for kw in [dict(), dict(use_dictionary=False), dict(data_page_version="2.0")]:
+        check(write_bytes(t, **kw), ctx, device_result=False)
+        check(write_bytes(t, **kw), ctx, device_result=True)
+
+
+def test_scan_feeds_the_filter_kernels_without_leaving_hbm(ctx):
+    """read_files -> filter as the reference's DAG runs them (read_files_task.rs:233-282 -> filter_task.rs:99), both on the
+    device: the decoded row group goes straight into filter_record; checked against the oracle on pyarrow's decode"""
+    n = 40_000
+    rng = np.random.default_rng(11)
+    t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "value1": pa.array(["%08x" % v for v in rng.integers(0, 2**32, n)]),
+                  "value2": pa.array((rng.random(n) * 100).astype(np.float32))})
+    raw = write_bytes(t, dictionary_pagesize_limit=16 * 1024, data_page_size=8 * 1024, row_group_size=25_000)
+    e = parse_expr("value2 > 10.0 and id % 3 = 0")
+    got_rows = 0
+    for g, dev in enumerate(chq.scan_parquet(raw, ctx=ctx)):
+        al = chq.get_record_table_aliases(None, dev)
+        out = chq.filter_record(dev, al, e, ctx=ctx).to_host()
+        host = pq.ParquetFile(io.BytesIO(raw)).read_row_group(g).to_batches()[0]
+        exp = O.filter_record(host, al, e)
+        assert out.equals(exp)
+        got_rows += out.num_rows
+    assert got_rows > 0
+
+
+def test_unsupported_features_say_so(ctx):
+    t = sample_table(100, seed=2)
+    f = chq.ParquetFile(write_bytes(t, compression="snappy"))
+    with pytest.raises(chq.ChqError) as e:
+        f.read_row_group(0, ctx=ctx)
+    assert e.value.code == 30 and "codec" in str(e.value)
+    f = chq.ParquetFile(write_bytes(pa.table({"d": pa.array([1, 2, 3], type=pa.date32())})))
+    with pytest.raises(chq.ChqError) as e:
+        f.read_row_group(0, ctx=ctx)
+    assert e.value.code == 30
+    f = chq.ParquetFile(write_bytes(pa.table({"v": pa.array(np.arange(1000, dtype=np.int64))}), use_dictionary=False,
+                                    column_encoding={"v": "DELTA_BINARY_PACKED"}))
+    with pytest.raises(chq.ChqError) as e:
+        f.read_row_group(0, ctx=ctx)
+    assert e.value.code == 30 and "encoding" in str(e.value)
+    with pytest.raises(chq.ChqError):
+        chq.ParquetFile(write_bytes(t)).read_row_group(5, ctx=ctx)

@@ -1,0 +1,89 @@
+"""CPU tier of the Parquet scan: the library's footer / page-header reader (a hand-written Thrift
+compact-protocol reader, `csrc/parquet_meta.cpp`) against pyarrow's own view of files pyarrow wrote.  No GPU: only
+`chq_parquet_open` / `chq_parquet_describe`."""
+import io
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+import chapterhouseqe_amd as chq
+from tests.parquet_cases import sample_table, write_bytes
+
+
+def parse(desc: str):
+    lines = desc.splitlines()
+    head = dict(zip(lines[0].split()[::2], lines[0].split()[1::2]))
+    cols = [l.split() for l in lines if l.startswith("column ")]
+    rgs, cur = [], None
+    for l in lines:
+        t = l.split()
+        if t[0] == "rg":
+            cur = {"rows": int(t[3]), "chunks": []}; rgs.append(cur)
+        elif t[0] == "chunk":
+            cur["chunks"].append({"values": int(t[3]), "codec": int(t[5]), "pages": []})
+        elif t[0] == "page":
+            cur["chunks"][-1]["pages"].append({"type": int(t[1]), "values": int(t[3]), "enc": int(t[5]), "bytes": int(t[7]), "header": int(t[9])})
+    return head, cols, rgs
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(use_dictionary=False), dict(data_page_version="2.0"), dict(data_page_size=512, row_group_size=3000),
+    dict(compression="snappy"), dict(use_dictionary=False, data_page_version="2.0", row_group_size=1000, write_statistics=False),
+])
+def test_metadata_matches_pyarrow(kw):
+    t = sample_table(7001, seed=3, nulls=True)
+    raw = write_bytes(t, **kw)
+    md = pq.ParquetFile(io.BytesIO(raw)).metadata
+    f = chq.ParquetFile(raw)
+    head, cols, rgs = parse(f.describe())
+    assert int(head["rows"]) == md.num_rows and int(head["row_groups"]) == md.num_row_groups == f.num_row_groups
+    assert [c[1] for c in cols] == [md.schema.column(i).name for i in range(md.num_columns)]
+    assert [c[2] for c in cols] == [md.schema.column(i).physical_type for i in range(md.num_columns)]
+    for g in range(md.num_row_groups):
+        assert rgs[g]["rows"] == md.row_group(g).num_rows == f.row_group_num_rows(g)
+        for c in range(md.num_columns):
+            cm = md.row_group(g).column(c)
+            ch = rgs[g]["chunks"][c]
+            assert ch["values"] == cm.num_values
+            assert (ch["codec"] == 0) == (cm.compression == "UNCOMPRESSED")
+            data_pages = [p for p in ch["pages"] if p["type"] in (0, 3)]
+            assert sum(p["values"] for p in data_pages) == cm.num_values
+            assert (len([p for p in ch["pages"] if p["type"] == 2]) == 1) == cm.has_dictionary_page
+            # the pages (header + payload each) tile the chunk exactly
+            assert sum(p["bytes"] + p["header"] for p in ch["pages"]) == cm.total_compressed_size
+    f.close()
+
+
+def test_malformed_files_are_rejected_with_a_message():
+    raw = write_bytes(sample_table(100, seed=1))
+    for bad in [b"", b"PAR1", raw[:-1], raw[:-4] + b"XXXX", b"XXXX" + raw[4:], raw[:len(raw) // 2] + raw[-8:]]:
+        with pytest.raises(chq.ChqError):
+            chq.ParquetFile(bad)
+    # a footer length that points outside the file
+    broken = bytearray(raw); broken[-8:-4] = (len(raw) * 2).to_bytes(4, "little")
+    with pytest.raises(chq.ChqError) as e:
+        chq.ParquetFile(bytes(broken))
+    assert "footer" in str(e.value)
+
+
+def test_nested_schemas_are_refused_at_open():
+    t = pa.table({"a": pa.array([[1, 2], [3]], type=pa.list_(pa.int32()))})
+    with pytest.raises(chq.ChqError) as e:
+        chq.ParquetFile(write_bytes(t))
+    assert e.value.code == 30 and "nested" in str(e.value)
+
+
+def test_the_reference_sample_shape():
+    """create_sample_data.rs writes id:Int32, value1:Utf8, value2:Float32 with default writer properties: uncompressed,
+    dictionary with PLAIN fallback, V1 pages -- the same settings here"""
+    n = 20_000
+    rng = np.random.default_rng(0)
+    t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "value1": pa.array(["%08x" % v for v in rng.integers(0, 2**32, n)]),
+                  "value2": pa.array(rng.random(n).astype(np.float32) * 100)})
+    f = chq.ParquetFile(write_bytes(t, dictionary_pagesize_limit=32 * 1024, data_page_size=16 * 1024))
+    head, cols, rgs = parse(f.describe())
+    assert [c[2] for c in cols] == ["INT32", "BYTE_ARRAY", "FLOAT"] and "utf8" in cols[1]
+    encs = {p["enc"] for ch in rgs[0]["chunks"] for p in ch["pages"] if p["type"] == 0}
+    assert encs == {0, 8}      # dictionary pages first, PLAIN after the dictionary outgrew its limit: both in one chunk
