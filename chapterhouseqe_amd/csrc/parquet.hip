@@ -12,7 +12,7 @@
 //   row values  pq_rowval_kernel        valid bytes                      -> value index per row (-1 = null)
 //   values      pq_plain_copy_kernel    PLAIN fixed-width pages          -> dense values (page headers squeezed out)
 //               pq_dict_fixed_kernel    RLE_DICTIONARY fixed-width pages -> dense values (dictionary applied)
-//               pq_bool_kernel          PLAIN BOOLEAN pages              -> one byte per value
+//               pq_bool_kernel, pq_bool_rle_kernel   PLAIN / RLE BOOLEAN pages -> one byte per value
 //               pq_ba_walk_kernel       PLAIN BYTE_ARRAY pages / dictionary page -> (position, length) per value
 //               pq_dict_ba_kernel       RLE_DICTIONARY BYTE_ARRAY pages  -> (position, length) per value
 //   rows        pq_gather_fixed_kernel, pq_pack_bits_kernel, pq_rowlen_* (offset scan), pq_utf8_copy_kernel
@@ -182,6 +182,21 @@ __global__ __launch_bounds__(256) void pq_bool_kernel(const PqDecodeParams p) {
   const uint8_t* src = p.chunk + d.values_at;
   uint8_t* out = p.dense + p.value_base[page];
   for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) out[k] = (src[k >> 3] >> (k & 7)) & 1;
+}
+
+// ---- RLE BOOLEAN pages (what V2 writers use): [4-byte length][hybrid runs, bit width 1] -> one byte per value ----------
+__global__ __launch_bounds__(64) void pq_bool_rle_kernel(const PqDecodeParams p) {
+  const int page = p.page_list[blockIdx.x], lane = threadIdx.x;
+  const PqPageDesc d = p.pages[page];
+  const uint32_t n = p.nonnull[page];
+  if (n == 0) return;
+  if (d.values_len < 4) { flag_error(p.err, PQ_ERR_VALUES); return; }
+  const uint8_t* v = p.chunk + d.values_at;
+  uint32_t len = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+  if (len > d.values_len - 4) { flag_error(p.err, PQ_ERR_VALUES); len = d.values_len - 4; }
+  uint8_t* out = p.dense + p.value_base[page];
+  const uint32_t got = hybrid_decode(v + 4, len, 1, n, lane, [&](uint32_t k, uint32_t b) { out[k] = (uint8_t)b; });
+  if (got != n) flag_error(p.err, PQ_ERR_VALUES);
 }
 
 // ---- PLAIN BYTE_ARRAY values (a data page, or the dictionary page): [4-byte length][bytes] ... --------------------------
@@ -389,6 +404,7 @@ hipError_t pq_launch_dict_fixed(const PqDecodeParams& p, int n_list, hipStream_t
   return hipGetLastError();
 }
 hipError_t pq_launch_bool(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_kernel, dim3(n_list), dim3(256), 0, s, p); return hipGetLastError(); }
+hipError_t pq_launch_bool_rle(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_rle_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_ba_walk(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_ba_walk_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_dict_ba(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_dict_ba_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_gather_fixed(const PqRowParams& p, int width, int grid, hipStream_t s) {

@@ -53,7 +53,9 @@ struct PqColumnChunk {
   int64_t stat_null_count = -1;   // from the chunk's Statistics, -1 = not recorded
   std::vector<int> encodings;
   std::vector<PqPage> pages;    // in file order, dictionary page (if any) first
-  int64_t first_byte() const { return dictionary_page_offset > 0 && dictionary_page_offset < data_page_offset ? dictionary_page_offset : data_page_offset; }
+  int64_t first_byte() const {   // (an empty chunk has a dictionary page and no data page: data_page_offset is 0 then)
+    return dictionary_page_offset > 0 && (data_page_offset <= 0 || dictionary_page_offset < data_page_offset) ? dictionary_page_offset : data_page_offset;
+  }
 };
 
 struct PqRowGroup {

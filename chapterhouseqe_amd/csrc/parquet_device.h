@@ -60,6 +60,7 @@ hipError_t pq_launch_rowval(const PqDecodeParams& p, hipStream_t s);
 hipError_t pq_launch_plain_copy(const PqDecodeParams& p, int n_list, hipStream_t s);
 hipError_t pq_launch_dict_fixed(const PqDecodeParams& p, int n_list, hipStream_t s);
 hipError_t pq_launch_bool(const PqDecodeParams& p, int n_list, hipStream_t s);
+hipError_t pq_launch_bool_rle(const PqDecodeParams& p, int n_list, hipStream_t s);
 hipError_t pq_launch_ba_walk(const PqDecodeParams& p, int n_list, hipStream_t s);
 hipError_t pq_launch_dict_ba(const PqDecodeParams& p, int n_list, hipStream_t s);
 hipError_t pq_launch_gather_fixed(const PqRowParams& p, int width, int grid, hipStream_t s);

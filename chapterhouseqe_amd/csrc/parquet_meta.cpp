@@ -233,6 +233,7 @@ PqFile parquet_open(const uint8_t* data, int64_t size) {
   for (PqRowGroup& rg : f.row_groups) {
     if (rg.columns.size() != f.columns.size()) bad("row group with " + std::to_string(rg.columns.size()) + " column chunks for " + std::to_string(f.columns.size()) + " columns");
     for (PqColumnChunk& c : rg.columns) {
+      if (c.num_values == 0) continue;   // an empty chunk: writers leave its offsets at 0
       int64_t at = c.first_byte();
       const int64_t chunk_end = at + c.total_compressed_size;
       if (at < 4 || chunk_end > size - 8) bad("column chunk outside the file");

@@ -73,7 +73,7 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
         w.format = "u"; w.byte_array = true; break;
       default: unsupported("physical type " + std::to_string(cs.type) + " of column '" + cs.name + "'");
     }
-    const int64_t first = cc.first_byte(), csize = cc.total_compressed_size;
+    const int64_t first = rows ? cc.first_byte() : 0, csize = rows ? cc.total_compressed_size : 0;
     if (csize >= (1ll << 32) - 64) unsupported("column chunk of " + std::to_string(csize) + " bytes");
     w.chunkb = make_device_buffer((size_t)csize + 64, ctx.device);
     check_hip(hipMemcpyAsync(w.chunkb->ptr, f.data + first, (size_t)csize, hipMemcpyHostToDevice, ctx.stream), "upload column chunk");
@@ -82,7 +82,7 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
     const bool optional = cs.repetition == 1;
     w.has_levels = optional && cc.stat_null_count != 0;
     std::vector<PqPageDesc> descs;
-    std::vector<int32_t> plain_list, dict_list;
+    std::vector<int32_t> plain_list, dict_list, rle_list;
     std::vector<uint32_t> h_nonnull, h_base;
     uint32_t dict_at = 0, dict_len = 0, dict_count = 0;
     bool have_dict = false;
@@ -126,7 +126,8 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       else if (pg.encoding == PQ_RLE_DICTIONARY || pg.encoding == PQ_PLAIN_DICTIONARY) {
         if (!have_dict) malformed("dictionary-encoded page without a dictionary page in front of it");
         dict_list.push_back(page_index);
-      } else unsupported("encoding " + std::to_string(pg.encoding) + " (column '" + cs.name + "')");
+      } else if (pg.encoding == PQ_RLE && w.boolean) rle_list.push_back(page_index);
+      else unsupported("encoding " + std::to_string(pg.encoding) + " (column '" + cs.name + "')");
       h_nonnull.push_back(d.num_rows); h_base.push_back((uint32_t)row_at);
       row_at += pg.num_values;
       descs.push_back(d);
@@ -153,8 +154,8 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       check_hip(pq_launch_rowval(p, ctx.stream), "launch pq_rowval_kernel");
     }
     // dense values: at most `rows` of them
-    auto plain_dev = upload(ctx, plain_list), dict_dev = upload(ctx, dict_list);
-    w.keep.push_back(plain_dev); w.keep.push_back(dict_dev);
+    auto plain_dev = upload(ctx, plain_list), dict_dev = upload(ctx, dict_list), rle_dev = upload(ctx, rle_list);
+    w.keep.push_back(plain_dev); w.keep.push_back(dict_dev); w.keep.push_back(rle_dev);
     if (w.byte_array) {
       w.vsrc = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
       w.vlen = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
@@ -188,6 +189,10 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
         p.page_list = (const int32_t*)plain_dev->ptr;
         if (w.boolean) check_hip(pq_launch_bool(p, (int)plain_list.size(), ctx.stream), "launch pq_bool_kernel");
         else check_hip(pq_launch_plain_copy(p, (int)plain_list.size(), ctx.stream), "launch pq_plain_copy_kernel");
+      }
+      if (!rle_list.empty()) {
+        p.page_list = (const int32_t*)rle_dev->ptr;
+        check_hip(pq_launch_bool_rle(p, (int)rle_list.size(), ctx.stream), "launch pq_bool_rle_kernel");
       }
       if (!dict_list.empty()) {
         if (w.boolean) unsupported("dictionary-encoded BOOLEAN column");
