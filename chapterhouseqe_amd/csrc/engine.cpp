@@ -118,6 +118,8 @@ BufferPtr make_host_buffer(size_t bytes) {
 Context::~Context() {
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
+  if (aux_fork) (void)hipEventDestroy(aux_fork);
+  for (int i = 0; i < kAuxStreams; ++i) { if (aux_join[i]) (void)hipEventDestroy(aux_join[i]); if (aux[i]) (void)hipStreamDestroy(aux[i]); }
   if (pinned) (void)hipHostFree(pinned);
   if (pinned_tbl) (void)hipHostFree(pinned_tbl);
   if (pinned_io) (void)hipHostFree(pinned_io);

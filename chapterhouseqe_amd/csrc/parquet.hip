@@ -3,10 +3,10 @@
 // CPU).  The host (parquet_meta.cpp / parquet_scan.cpp) parses only metadata and uploads each column chunk as it lies in
 // the file; everything per value happens here.
 //
-// Work split: pages are independent, so the inherently serial parts -- walking the run headers of the RLE / bit-packed
-// hybrid encoding, walking the length prefixes of PLAIN BYTE_ARRAY values -- run ONE WAVE PER PAGE (the wave expands each
-// run with all 64 lanes; the length walk is staged through LDS so that its dependent loads have LDS, not HBM, latency),
-// and every per-row step (rank -> value, gathers, offset scan, byte copies) is a plain data-parallel kernel.
+// Work split: pages are independent, so the inherently serial parts run one workgroup (run headers of the RLE / bit-packed
+// hybrid: 256 threads expand each run) or one wave (length prefixes of PLAIN BYTE_ARRAY values, 64 speculative positions
+// per step) PER PAGE, staged through LDS so that the dependent loads have LDS, not HBM, latency; every per-row step
+// (rank -> value, gathers, offset scan, byte copies) is a plain data-parallel kernel.
 //   levels      pq_levels_kernel        definition levels (bit width 1)   -> one byte per row + non-null count per page
 //   page scan   pq_page_scan_kernel     non-null counts                  -> first value index of every page
 //   row values  pq_rowval_kernel        valid bytes                      -> value index per row (-1 = null)
@@ -36,64 +36,89 @@ __device__ __forceinline__ unsigned lane_rank64(unsigned long long m) {
 }
 __device__ __forceinline__ void flag_error(uint32_t* err, uint32_t code) { atomicMax(err, code); }
 
-// The RLE / bit-packed hybrid of Parquet (definition levels, dictionary indices): a sequence of runs, each introduced by
-// a varint header h -- (h & 1) == 0: RLE, h >> 1 repetitions of one value stored in ceil(bw / 8) bytes; (h & 1) == 1:
-// bit-packed, (h >> 1) groups of 8 values, bw bits each, LSB first.  The whole wave walks the headers together (uniform
-// scalar work), then expands the run with all lanes; `emit(k, v)` receives value v for position k < n.  Returns the
-// number of values emitted (n unless the stream ends early).
-template <typename Emit>
-__device__ __forceinline__ uint32_t hybrid_decode(const uint8_t* p, uint32_t len, int bw, uint32_t n, int lane, Emit&& emit) {
-  uint32_t pos = 0, k = 0;
+// The RLE / bit-packed hybrid of Parquet (definition levels, dictionary indices, RLE booleans): a sequence of runs, each
+// introduced by a varint header h -- (h & 1) == 0: RLE, h >> 1 repetitions of one value stored in ceil(bw / 8) bytes;
+// (h & 1) == 1: bit-packed, (h >> 1) groups of 8 values, bw bits each, LSB first.  `emit(k, v)` receives value v for
+// position k < n; returns the number of values emitted (n unless the stream ends early).
+// One workgroup per page, the stream staged through LDS: the run headers are parsed by every thread
+// from LDS (identical scalar work, no dependent HBM loads), each run is expanded by all BLOCK threads, bit-packed values
+// are extracted from LDS.  A bit-packed run that does not fit the window continues after the next staging.
+constexpr int PQ_HYB_WINDOW = 16384;   // bytes
+template <int BLOCK, typename Emit>
+__device__ __forceinline__ uint32_t hybrid_decode_block(const uint8_t* g, uint32_t len, int bw, uint32_t n, uint32_t* s_win, Emit&& emit) {
+  const int tid = threadIdx.x;
+  const uint8_t* sb = (const uint8_t*)s_win;
   const int vbytes = (bw + 7) >> 3;
   const uint32_t mask = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1u);
+  uint32_t pos = 0, k = 0, pending = 0;   // pending: groups of a bit-packed run still to come
   while (k < n && pos < len) {
-    uint32_t h = 0;
-    for (int shift = 0; shift < 35 && pos < len; shift += 7) { const uint8_t b = p[pos++]; h |= (uint32_t)(b & 0x7f) << shift; if (!(b & 0x80)) break; }
-    if ((h & 1u) == 0) {
-      uint32_t cnt = h >> 1;
-      uint32_t v = 0;
-      for (int b = 0; b < vbytes && pos < len; ++b) v |= (uint32_t)p[pos++] << (8 * b);
-      v &= mask;
+    const uint8_t* a = (const uint8_t*)((uintptr_t)(g + pos) & ~(uintptr_t)3);
+    const uint32_t shift = (uint32_t)((g + pos) - a);
+    const uint32_t wpos = pos;
+    const uint32_t wbytes = len - pos < (uint32_t)(PQ_HYB_WINDOW - 16) ? len - pos : (uint32_t)(PQ_HYB_WINDOW - 16);
+    for (uint32_t i = tid; i < (shift + wbytes + 3) / 4 + 2; i += BLOCK) s_win[i] = ((const uint32_t*)a)[i];   // (chunk buffers are padded by 64 bytes)
+    __syncthreads();
+    const uint32_t wend = pos + wbytes;
+    bool stop = false;
+    while (k < n && pos < wend && !stop) {
+      uint32_t groups;
+      if (pending) { groups = pending; pending = 0; }
+      else {
+        if (pos + 9 > wend && wend < len) break;            // header (<= 5 bytes) + RLE value (<= 4) may straddle the window
+        uint32_t h = 0;
+        for (int sh = 0; sh < 35 && pos < wend; sh += 7) { const uint8_t b = sb[pos - wpos + shift]; ++pos; h |= (uint32_t)(b & 0x7f) << sh; if (!(b & 0x80)) break; }
+        if ((h & 1u) == 0) {
+          uint32_t cnt = h >> 1, v = 0;
+          for (int b = 0; b < vbytes && pos < wend; ++b) { v |= (uint32_t)sb[pos - wpos + shift] << (8 * b); ++pos; }
+          v &= mask;
+          if (cnt > n - k) cnt = n - k;
+          for (uint32_t i = tid; i < cnt; i += BLOCK) emit(k + i, v);
+          k += cnt;
+          continue;
+        }
+        groups = h >> 1;
+      }
+      const uint32_t fit = bw ? (wend - pos) / (uint32_t)bw : groups;   // whole groups (bw bytes each) inside the window
+      const uint32_t now = groups < fit ? groups : fit;
+      if (now == 0) { if (wend >= len) stop = true; else pending = groups; break; }
+      uint32_t cnt = now * 8u;
       if (cnt > n - k) cnt = n - k;
-      for (uint32_t i = lane; i < cnt; i += 64) emit(k + i, v);
-      k += cnt;
-    } else {
-      const uint32_t groups = h >> 1;
-      uint32_t cnt = groups * 8u;
-      const uint32_t bytes = groups * (uint32_t)bw;
-      uint32_t avail = cnt;
-      if (pos + bytes > len) avail = bw ? ((len - pos) * 8u) / (uint32_t)bw : cnt;   // truncated stream: what is there
-      if (cnt > n - k) cnt = n - k;
-      if (cnt > avail) cnt = avail;
-      for (uint32_t i = lane; i < cnt; i += 64) {
+      for (uint32_t i = tid; i < cnt; i += BLOCK) {
         const uint64_t bit = (uint64_t)i * (uint32_t)bw;
-        const uint8_t* q = p + pos + (bit >> 3);
-        uint64_t w = 0;   // up to 5 bytes are needed; the chunk buffer is padded, but never read past the run itself
-        const uint32_t left = pos + bytes - (uint32_t)(pos + (bit >> 3));
-        if (left >= 8) __builtin_memcpy(&w, q, 8);
-        else for (uint32_t b = 0; b < left; ++b) w |= (uint64_t)q[b] << (8 * b);
+        const uint32_t off = pos - wpos + shift + (uint32_t)(bit >> 3);
+        const uint32_t d0 = s_win[off >> 2], d1 = s_win[(off >> 2) + 1], d2 = s_win[(off >> 2) + 2];
+        const uint64_t w = (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, off & 3) | (uint64_t)__builtin_amdgcn_alignbyte(d2, d1, off & 3) << 32;
         emit(k + i, (uint32_t)(w >> (bit & 7)) & mask);
       }
       k += cnt;
-      pos += bytes;
+      pos += now * (uint32_t)bw;
+      if (now < groups) { pending = groups - now; break; }
     }
+    __syncthreads();
+    if (stop) break;
   }
   return k;
 }
+constexpr int PQ_HYB_BLOCK = 256;
 
 }  // namespace
 
 // ---- definition levels: one byte per row, non-null count per page -----------------------------------------------------
-__global__ __launch_bounds__(64) void pq_levels_kernel(const PqDecodeParams p) {
-  const int page = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(PQ_HYB_BLOCK) void pq_levels_kernel(const PqDecodeParams p) {
+  __shared__ uint32_t s_win[PQ_HYB_WINDOW / 4 + 4];
+  __shared__ uint32_t s_ones;
+  const int page = blockIdx.x;
   const PqPageDesc d = p.pages[page];
   uint8_t* valid = p.valid8 + d.first_row;
+  if (threadIdx.x == 0) s_ones = 0;
   uint32_t ones = 0;
-  const uint32_t got = hybrid_decode(p.chunk + d.levels_at, d.levels_len, 1, d.num_rows, lane,
-                                     [&](uint32_t k, uint32_t v) { valid[k] = (uint8_t)v; ones += v; });
-  if (got != d.num_rows) flag_error(p.err, PQ_ERR_LEVELS);
+  const uint32_t got = hybrid_decode_block<PQ_HYB_BLOCK>(p.chunk + d.levels_at, d.levels_len, 1, d.num_rows, s_win,
+                                                         [&](uint32_t k, uint32_t v) { valid[k] = (uint8_t)v; ones += v; });
+  if (got != d.num_rows && threadIdx.x == 0) flag_error(p.err, PQ_ERR_LEVELS);
   ones = wave_sum_u32(ones);
-  if (lane == 0) p.nonnull[page] = ones;
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_ones, ones);
+  __syncthreads();
+  if (threadIdx.x == 0) p.nonnull[page] = s_ones;
 }
 
 // ---- first value index of every page (exclusive scan of the non-null counts; one block) -------------------------------
@@ -153,24 +178,25 @@ __global__ __launch_bounds__(256) void pq_plain_copy_kernel(const PqDecodeParams
 
 // ---- RLE_DICTIONARY pages of a fixed-width column: decode the indices, apply the dictionary ---------------------------
 template <typename TY>
-__global__ __launch_bounds__(64) void pq_dict_fixed_kernel(const PqDecodeParams p) {
-  const int page = p.page_list[blockIdx.x], lane = threadIdx.x;
+__global__ __launch_bounds__(PQ_HYB_BLOCK) void pq_dict_fixed_kernel(const PqDecodeParams p) {
+  __shared__ uint32_t s_win[PQ_HYB_WINDOW / 4 + 4];
+  const int page = p.page_list[blockIdx.x];
   const PqPageDesc d = p.pages[page];
   const uint32_t n = p.nonnull[page];
   if (n == 0) return;
-  if (d.values_len < 1) { flag_error(p.err, PQ_ERR_VALUES); return; }
+  if (d.values_len < 1) { if (threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES); return; }
   const uint8_t* v = p.chunk + d.values_at;
   const int bw = v[0];
-  if (bw > 32) { flag_error(p.err, PQ_ERR_VALUES); return; }
+  if (bw > 32) { if (threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES); return; }
   TY* out = (TY*)p.dense + p.value_base[page];
   const uint8_t* dict = p.chunk + p.dict_at;
   bool bad_index = false;
-  const uint32_t got = hybrid_decode(v + 1, d.values_len - 1, bw, n, lane, [&](uint32_t k, uint32_t idx) {
+  const uint32_t got = hybrid_decode_block<PQ_HYB_BLOCK>(v + 1, d.values_len - 1, bw, n, s_win, [&](uint32_t k, uint32_t idx) {
     if (idx >= p.dict_count) { bad_index = true; idx = 0; }
     TY w; __builtin_memcpy(&w, dict + (uint64_t)idx * sizeof(TY), sizeof(TY));
     out[k] = w;
   });
-  if (got != n || __ballot(bad_index)) flag_error(p.err, PQ_ERR_VALUES);
+  if (got != n || bad_index) flag_error(p.err, PQ_ERR_VALUES);
 }
 
 // ---- PLAIN BOOLEAN pages: bit-packed, LSB first -> one byte per value --------------------------------------------------
@@ -185,30 +211,31 @@ __global__ __launch_bounds__(256) void pq_bool_kernel(const PqDecodeParams p) {
 }
 
 // ---- RLE BOOLEAN pages (what V2 writers use): [4-byte length][hybrid runs, bit width 1] -> one byte per value ----------
-__global__ __launch_bounds__(64) void pq_bool_rle_kernel(const PqDecodeParams p) {
-  const int page = p.page_list[blockIdx.x], lane = threadIdx.x;
+__global__ __launch_bounds__(PQ_HYB_BLOCK) void pq_bool_rle_kernel(const PqDecodeParams p) {
+  __shared__ uint32_t s_win[PQ_HYB_WINDOW / 4 + 4];
+  const int page = p.page_list[blockIdx.x];
   const PqPageDesc d = p.pages[page];
   const uint32_t n = p.nonnull[page];
   if (n == 0) return;
-  if (d.values_len < 4) { flag_error(p.err, PQ_ERR_VALUES); return; }
+  if (d.values_len < 4) { if (threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES); return; }
   const uint8_t* v = p.chunk + d.values_at;
   uint32_t len = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
-  if (len > d.values_len - 4) { flag_error(p.err, PQ_ERR_VALUES); len = d.values_len - 4; }
+  if (len > d.values_len - 4) { if (threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES); len = d.values_len - 4; }
   uint8_t* out = p.dense + p.value_base[page];
-  const uint32_t got = hybrid_decode(v + 4, len, 1, n, lane, [&](uint32_t k, uint32_t b) { out[k] = (uint8_t)b; });
-  if (got != n) flag_error(p.err, PQ_ERR_VALUES);
+  const uint32_t got = hybrid_decode_block<PQ_HYB_BLOCK>(v + 4, len, 1, n, s_win, [&](uint32_t k, uint32_t b) { out[k] = (uint8_t)b; });
+  if (got != n && threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES);
 }
 
 // ---- PLAIN BYTE_ARRAY values (a data page, or the dictionary page): [4-byte length][bytes] ... --------------------------
 // The position of value k+1 depends on the length of value k: the walk is serial per page.  One wave per page: a window
-// of the page is staged in LDS by all lanes, lane 0 walks the length prefixes inside it (dependent LDS reads instead of
-// dependent HBM reads), the (position, length) pairs it finds are collected in LDS and written out by all lanes.
-constexpr int PQ_WALK_WINDOW = 16384;   // bytes
-constexpr int PQ_WALK_BATCH = 1024;     // values
+// of the page is staged in LDS by all lanes (dependent LDS reads instead of dependent HBM reads), and every step is
+// SPECULATIVE: with L the length found at the current position, lane l looks at position + l * (4 + L) and checks that
+// the length prefix there is L too; the lanes up to the first disagreement are confirmed together (each one's position
+// follows from its predecessor's length).  Columns of equal-length strings (keys, codes, hashes, the reference's sample
+// data) advance 64 values per step, ragged ones at least one.
+constexpr int PQ_WALK_WINDOW = 32768;   // bytes
 __global__ __launch_bounds__(64) void pq_ba_walk_kernel(const PqDecodeParams p) {
   __shared__ uint32_t s_win[PQ_WALK_WINDOW / 4 + 2];
-  __shared__ uint32_t s_src[PQ_WALK_BATCH], s_len[PQ_WALK_BATCH];
-  __shared__ uint32_t s_state[3];   // values found in this round, next position, error
   const int lane = threadIdx.x;
   uint32_t values_at, values_len, n; uint32_t* osrc; uint32_t* olen;
   if (p.walk_dictionary) {
@@ -220,60 +247,60 @@ __global__ __launch_bounds__(64) void pq_ba_walk_kernel(const PqDecodeParams p) 
     osrc = p.vsrc + p.value_base[page]; olen = p.vlen + p.value_base[page];
   }
   const uint32_t end = values_at + values_len;
-  uint32_t pos = values_at, k = 0;
-  while (k < n) {
-    // stage [wbase, wbase + WINDOW): wbase is pos rounded down to a multiple of 4 (dword loads of the chunk buffer)
-    const uint32_t wbase = pos & ~3u;
+  uint32_t q = values_at, k = 0;
+  bool failed = false;
+  while (k < n && !failed) {
+    // stage [wbase, wbase + wbytes): wbase is q rounded down to a multiple of 4 (dword loads of the chunk buffer)
+    const uint32_t wbase = q & ~3u;
     const uint32_t* g = (const uint32_t*)(p.chunk + wbase);
     const uint32_t wbytes = end - wbase < (uint32_t)PQ_WALK_WINDOW ? end - wbase : (uint32_t)PQ_WALK_WINDOW;
-    for (uint32_t i = lane; i < (wbytes + 3) / 4 + 1; i += 64) s_win[i] = g[i];   // (the chunk buffer is padded by 16 bytes)
+    for (uint32_t i = lane; i < (wbytes + 3) / 4 + 1; i += 64) s_win[i] = g[i];   // (the chunk buffer is padded by 64 bytes)
     __syncthreads();
-    if (lane == 0) {
-      uint32_t found = 0, q = pos, e = 0;
-      while (k + found < n && found < (uint32_t)PQ_WALK_BATCH) {
-        if (q + 4 > end) { e = 1; break; }
-        const uint32_t off = q - wbase;
-        if (off + 4 > wbytes) break;                       // the next length prefix lies outside the window: restage
-        const uint32_t lo = s_win[off >> 2], hi = s_win[(off >> 2) + 1];
-        const uint32_t len = __builtin_amdgcn_alignbyte(hi, lo, off & 3);
-        if (len > end - q - 4) { e = 1; break; }
-        s_src[found] = q + 4; s_len[found] = len;
-        ++found;
-        q += 4 + len;
-      }
-      s_state[0] = found; s_state[1] = q; s_state[2] = e;
+    auto length_at = [&](uint32_t pos) {   // pos + 4 <= wbase + wbytes
+      const uint32_t off = pos - wbase;
+      return (uint32_t)__builtin_amdgcn_alignbyte(s_win[(off >> 2) + 1], s_win[off >> 2], off & 3);
+    };
+    while (k < n) {
+      if (q + 4 > end) { failed = true; break; }
+      if (q + 4 > wbase + wbytes) break;                       // the next length prefix lies outside the window: restage
+      const uint32_t L = length_at(q);                          // (uniform)
+      if (L > end - q - 4) { failed = true; break; }
+      const uint64_t c = (uint64_t)q + (uint64_t)lane * (4ull + L);
+      bool ok = k + lane < n && c + 4 <= (uint64_t)wbase + wbytes && c + 4 + L <= end;
+      if (ok) ok = length_at((uint32_t)c) == L;
+      const unsigned long long m = __ballot(ok);
+      const int cnt = m == ~0ull ? 64 : __builtin_ctzll(~m);   // lane 0 always agrees with itself: cnt >= 1
+      if (lane < cnt) { osrc[k + lane] = (uint32_t)c + 4; olen[k + lane] = L; }
+      k += (uint32_t)cnt;
+      q += (uint32_t)cnt * (4u + L);
     }
     __syncthreads();
-    const uint32_t found = s_state[0];
-    for (uint32_t i = lane; i < found; i += 64) { osrc[k + i] = s_src[i]; olen[k + i] = s_len[i]; }
-    k += found; pos = s_state[1];
-    if (s_state[2]) {   // malformed page: the rest reads as empty strings
-      if (lane == 0) flag_error(p.err, PQ_ERR_VALUES);
-      for (uint32_t i = k + lane; i < n; i += 64) { osrc[i] = values_at; olen[i] = 0; }
-      break;
-    }
-    __syncthreads();
+  }
+  if (failed) {   // malformed page: the rest reads as empty strings
+    if (lane == 0) flag_error(p.err, PQ_ERR_VALUES);
+    for (uint32_t i = k + lane; i < n; i += 64) { osrc[i] = values_at; olen[i] = 0; }
   }
 }
 
 // ---- RLE_DICTIONARY pages of a BYTE_ARRAY column: index -> (position, length) of the dictionary entry ------------------
-__global__ __launch_bounds__(64) void pq_dict_ba_kernel(const PqDecodeParams p) {
-  const int page = p.page_list[blockIdx.x], lane = threadIdx.x;
+__global__ __launch_bounds__(PQ_HYB_BLOCK) void pq_dict_ba_kernel(const PqDecodeParams p) {
+  __shared__ uint32_t s_win[PQ_HYB_WINDOW / 4 + 4];
+  const int page = p.page_list[blockIdx.x];
   const PqPageDesc d = p.pages[page];
   const uint32_t n = p.nonnull[page];
   if (n == 0) return;
-  if (d.values_len < 1) { flag_error(p.err, PQ_ERR_VALUES); return; }
+  if (d.values_len < 1) { if (threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES); return; }
   const uint8_t* v = p.chunk + d.values_at;
   const int bw = v[0];
-  if (bw > 32) { flag_error(p.err, PQ_ERR_VALUES); return; }
+  if (bw > 32) { if (threadIdx.x == 0) flag_error(p.err, PQ_ERR_VALUES); return; }
   uint32_t* osrc = p.vsrc + p.value_base[page];
   uint32_t* olen = p.vlen + p.value_base[page];
   bool bad_index = false;
-  const uint32_t got = hybrid_decode(v + 1, d.values_len - 1, bw, n, lane, [&](uint32_t k, uint32_t idx) {
+  const uint32_t got = hybrid_decode_block<PQ_HYB_BLOCK>(v + 1, d.values_len - 1, bw, n, s_win, [&](uint32_t k, uint32_t idx) {
     if (idx >= p.dict_count) { bad_index = true; osrc[k] = d.values_at; olen[k] = 0; return; }
     osrc[k] = p.dict_src[idx]; olen[k] = p.dict_len_out[idx];
   });
-  if (got != n || __ballot(bad_index)) flag_error(p.err, PQ_ERR_VALUES);
+  if (got != n || bad_index) flag_error(p.err, PQ_ERR_VALUES);
 }
 
 // ---- rows ------------------------------------------------------------------------------------------------------------
@@ -391,22 +418,22 @@ __global__ __launch_bounds__(256) void pq_utf8_copy_kernel(const PqRowParams p) 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
-hipError_t pq_launch_levels(const PqDecodeParams& p, hipStream_t s) { hipLaunchKernelGGL(pq_levels_kernel, dim3(p.n_pages), dim3(64), 0, s, p); return hipGetLastError(); }
+hipError_t pq_launch_levels(const PqDecodeParams& p, hipStream_t s) { hipLaunchKernelGGL(pq_levels_kernel, dim3(p.n_pages), dim3(PQ_HYB_BLOCK), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_page_scan(const PqDecodeParams& p, hipStream_t s) { hipLaunchKernelGGL(pq_page_scan_kernel, dim3(1), dim3(256), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_rowval(const PqDecodeParams& p, hipStream_t s) { hipLaunchKernelGGL(pq_rowval_kernel, dim3(p.n_pages), dim3(64), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_plain_copy(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_plain_copy_kernel, dim3(n_list, 16), dim3(256), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_dict_fixed(const PqDecodeParams& p, int n_list, hipStream_t s) {
   switch (p.width) {
-    case 4: hipLaunchKernelGGL(pq_dict_fixed_kernel<uint32_t>, dim3(n_list), dim3(64), 0, s, p); break;
-    case 8: hipLaunchKernelGGL(pq_dict_fixed_kernel<uint64_t>, dim3(n_list), dim3(64), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pq_dict_fixed_kernel<uint32_t>, dim3(n_list), dim3(PQ_HYB_BLOCK), 0, s, p); break;
+    case 8: hipLaunchKernelGGL(pq_dict_fixed_kernel<uint64_t>, dim3(n_list), dim3(PQ_HYB_BLOCK), 0, s, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 hipError_t pq_launch_bool(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_kernel, dim3(n_list), dim3(256), 0, s, p); return hipGetLastError(); }
-hipError_t pq_launch_bool_rle(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_rle_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
+hipError_t pq_launch_bool_rle(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_rle_kernel, dim3(n_list), dim3(PQ_HYB_BLOCK), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_ba_walk(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_ba_walk_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
-hipError_t pq_launch_dict_ba(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_dict_ba_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
+hipError_t pq_launch_dict_ba(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_dict_ba_kernel, dim3(n_list), dim3(PQ_HYB_BLOCK), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_gather_fixed(const PqRowParams& p, int width, int grid, hipStream_t s) {
   switch (width) {
     case 4: hipLaunchKernelGGL(pq_gather_fixed_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, p); break;

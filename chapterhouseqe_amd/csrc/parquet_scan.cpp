@@ -12,10 +12,38 @@ namespace {
 [[noreturn]] void malformed(const std::string& what) { throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: " + what}; }
 
 template <typename T>
-BufferPtr upload(Context& ctx, const std::vector<T>& v) {
+BufferPtr upload(Context& ctx, hipStream_t stream, const std::vector<T>& v) {
   auto b = make_device_buffer(v.size() * sizeof(T) + 16, ctx.device);
-  if (!v.empty()) check_hip(hipMemcpyAsync(b->ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx.stream), "upload page table");
+  if (!v.empty()) check_hip(hipMemcpyAsync(b->ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream), "upload page table");
   return b;
+}
+
+// the columns' streams: forked off ctx.stream, joined back into it
+void fork_streams(Context& ctx) {
+  if (!ctx.aux_fork) {
+    check_hip(hipEventCreateWithFlags(&ctx.aux_fork, hipEventDisableTiming), "hipEventCreate");
+    for (int i = 0; i < Context::kAuxStreams; ++i) {
+      check_hip(hipStreamCreateWithFlags(&ctx.aux[i], hipStreamNonBlocking), "hipStreamCreate");
+      check_hip(hipEventCreateWithFlags(&ctx.aux_join[i], hipEventDisableTiming), "hipEventCreate");
+    }
+  }
+  check_hip(hipEventRecord(ctx.aux_fork, ctx.stream), "hipEventRecord");
+  for (int i = 0; i < Context::kAuxStreams; ++i) check_hip(hipStreamWaitEvent(ctx.aux[i], ctx.aux_fork, 0), "hipStreamWaitEvent");
+}
+// an error thrown while columns are in flight: wait for them before their temporaries go back to the pool
+struct DrainOnUnwind {
+  Context& ctx;
+  ~DrainOnUnwind() {
+    if (!ctx.aux_fork) return;
+    for (int i = 0; i < Context::kAuxStreams; ++i) (void)hipStreamSynchronize(ctx.aux[i]);
+    (void)hipStreamSynchronize(ctx.stream);
+  }
+};
+void join_streams(Context& ctx) {
+  for (int i = 0; i < Context::kAuxStreams; ++i) {
+    check_hip(hipEventRecord(ctx.aux_join[i], ctx.aux[i]), "hipEventRecord");
+    check_hip(hipStreamWaitEvent(ctx.stream, ctx.aux_join[i], 0), "hipStreamWaitEvent");
+  }
 }
 
 struct Scalars {   // per column, on the device and read back once per phase
@@ -45,12 +73,15 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
   if (rows < 0 || rows >= (1ll << 31)) unsupported("row group of " + std::to_string(rows) + " rows");
   const size_t nc = f.columns.size();
   std::vector<ColumnWork> work(nc);
+  DrainOnUnwind drain{ctx};   // (declared after `work`: runs before the buffers are released)
   auto scal = make_device_buffer(sizeof(Scalars) * (nc + 1), ctx.device);
   check_hip(hipMemsetAsync(scal->ptr, 0, sizeof(Scalars) * (nc + 1), ctx.stream), "memset");
   Scalars* dscal = (Scalars*)scal->ptr;
 
-  // ---- phase A: everything up to the Utf8 offsets --------------------------------------------------------------------
+  // ---- phase A: everything up to the Utf8 offsets, the columns side by side on their own streams -----------------------
+  fork_streams(ctx);
   for (size_t ci = 0; ci < nc; ++ci) {
+    const hipStream_t cstream = ctx.aux[ci % Context::kAuxStreams];
     const PqColumnSchema& cs = f.columns[ci];
     const PqColumnChunk& cc = rg.columns[ci];
     ColumnWork& w = work[ci];
@@ -76,8 +107,8 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
     const int64_t first = rows ? cc.first_byte() : 0, csize = rows ? cc.total_compressed_size : 0;
     if (csize >= (1ll << 32) - 64) unsupported("column chunk of " + std::to_string(csize) + " bytes");
     w.chunkb = make_device_buffer((size_t)csize + 64, ctx.device);
-    check_hip(hipMemcpyAsync(w.chunkb->ptr, f.data + first, (size_t)csize, hipMemcpyHostToDevice, ctx.stream), "upload column chunk");
-    check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + csize, 0, 64, ctx.stream), "memset");
+    check_hip(hipMemcpyAsync(w.chunkb->ptr, f.data + first, (size_t)csize, hipMemcpyHostToDevice, cstream), "upload column chunk");
+    check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + csize, 0, 64, cstream), "memset");
 
     const bool optional = cs.repetition == 1;
     w.has_levels = optional && cc.stat_null_count != 0;
@@ -134,9 +165,9 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
     }
     if (row_at != rows) malformed("pages of column '" + cs.name + "' hold " + std::to_string(row_at) + " rows, the row group has " + std::to_string(rows));
     const int n_pages = (int)descs.size();
-    w.pages = upload(ctx, descs);
-    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, h_nonnull);
-    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, h_base);
+    w.pages = upload(ctx, cstream, descs);
+    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_nonnull);
+    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_base);
     w.host_values = rows;
 
     PqDecodeParams p{};
@@ -149,12 +180,12 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       w.valid8 = make_device_buffer((size_t)rows + 64, ctx.device);
       w.row_val = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
       p.valid8 = (uint8_t*)w.valid8->ptr; p.row_val = (int32_t*)w.row_val->ptr;
-      check_hip(pq_launch_levels(p, ctx.stream), "launch pq_levels_kernel");
-      check_hip(pq_launch_page_scan(p, ctx.stream), "launch pq_page_scan_kernel");
-      check_hip(pq_launch_rowval(p, ctx.stream), "launch pq_rowval_kernel");
+      check_hip(pq_launch_levels(p, cstream), "launch pq_levels_kernel");
+      check_hip(pq_launch_page_scan(p, cstream), "launch pq_page_scan_kernel");
+      check_hip(pq_launch_rowval(p, cstream), "launch pq_rowval_kernel");
     }
     // dense values: at most `rows` of them
-    auto plain_dev = upload(ctx, plain_list), dict_dev = upload(ctx, dict_list), rle_dev = upload(ctx, rle_list);
+    auto plain_dev = upload(ctx, cstream, plain_list), dict_dev = upload(ctx, cstream, dict_list), rle_dev = upload(ctx, cstream, rle_list);
     w.keep.push_back(plain_dev); w.keep.push_back(dict_dev); w.keep.push_back(rle_dev);
     if (w.byte_array) {
       w.vsrc = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
@@ -164,13 +195,13 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
         w.dict_src = make_device_buffer((size_t)dict_count * 4 + 64, ctx.device);
         w.dict_len = make_device_buffer((size_t)dict_count * 4 + 64, ctx.device);
         p.dict_src = (uint32_t*)w.dict_src->ptr; p.dict_len_out = (uint32_t*)w.dict_len->ptr;
-        if (dict_count > 0) { p.walk_dictionary = 1; check_hip(pq_launch_ba_walk(p, 1, ctx.stream), "launch pq_ba_walk_kernel (dictionary)"); p.walk_dictionary = 0; }
+        if (dict_count > 0) { p.walk_dictionary = 1; check_hip(pq_launch_ba_walk(p, 1, cstream), "launch pq_ba_walk_kernel (dictionary)"); p.walk_dictionary = 0; }
         p.page_list = (const int32_t*)dict_dev->ptr;
-        check_hip(pq_launch_dict_ba(p, (int)dict_list.size(), ctx.stream), "launch pq_dict_ba_kernel");
+        check_hip(pq_launch_dict_ba(p, (int)dict_list.size(), cstream), "launch pq_dict_ba_kernel");
       }
       if (!plain_list.empty()) {
         p.page_list = (const int32_t*)plain_dev->ptr;
-        check_hip(pq_launch_ba_walk(p, (int)plain_list.size(), ctx.stream), "launch pq_ba_walk_kernel");
+        check_hip(pq_launch_ba_walk(p, (int)plain_list.size(), cstream), "launch pq_ba_walk_kernel");
       }
       // offsets = exclusive scan of the row lengths
       w.offsets = make_device_buffer((size_t)(rows + 2) * 4, ctx.device);
@@ -180,27 +211,28 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       r.n_rows = rows; r.row_val = w.has_levels ? (const int32_t*)w.row_val->ptr : nullptr;
       r.vlen = (const uint32_t*)w.vlen->ptr; r.out = w.offsets->ptr;
       r.block_sums = (unsigned long long*)w.block_sums->ptr; r.n_blocks = n_blocks; r.total_bytes = &dscal[ci].total_bytes;
-      check_hip(pq_launch_rowlen(r, ctx.stream), "launch pq_rowlen kernels");
+      check_hip(pq_launch_rowlen(r, cstream), "launch pq_rowlen kernels");
     } else {
       if (dict_count > 0 && (uint64_t)dict_count * w.width > dict_len) malformed("dictionary page shorter than its entries");
       w.dense = make_device_buffer((size_t)rows * w.width + 64, ctx.device);
       p.dense = (uint8_t*)w.dense->ptr;
       if (!plain_list.empty()) {
         p.page_list = (const int32_t*)plain_dev->ptr;
-        if (w.boolean) check_hip(pq_launch_bool(p, (int)plain_list.size(), ctx.stream), "launch pq_bool_kernel");
-        else check_hip(pq_launch_plain_copy(p, (int)plain_list.size(), ctx.stream), "launch pq_plain_copy_kernel");
+        if (w.boolean) check_hip(pq_launch_bool(p, (int)plain_list.size(), cstream), "launch pq_bool_kernel");
+        else check_hip(pq_launch_plain_copy(p, (int)plain_list.size(), cstream), "launch pq_plain_copy_kernel");
       }
       if (!rle_list.empty()) {
         p.page_list = (const int32_t*)rle_dev->ptr;
-        check_hip(pq_launch_bool_rle(p, (int)rle_list.size(), ctx.stream), "launch pq_bool_rle_kernel");
+        check_hip(pq_launch_bool_rle(p, (int)rle_list.size(), cstream), "launch pq_bool_rle_kernel");
       }
       if (!dict_list.empty()) {
         if (w.boolean) unsupported("dictionary-encoded BOOLEAN column");
         p.page_list = (const int32_t*)dict_dev->ptr;
-        check_hip(pq_launch_dict_fixed(p, (int)dict_list.size(), ctx.stream), "launch pq_dict_fixed_kernel");
+        check_hip(pq_launch_dict_fixed(p, (int)dict_list.size(), cstream), "launch pq_dict_fixed_kernel");
       }
     }
   }
+  join_streams(ctx);
   std::vector<Scalars> hs(nc + 1);
   check_hip(hipMemcpyAsync(hs.data(), scal->ptr, sizeof(Scalars) * nc, hipMemcpyDeviceToHost, ctx.stream), "read back");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
@@ -209,7 +241,9 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
   Batch out;
   out.on_device = true; out.device_id = ctx.device; out.nrows = rows;
   const int grid = ctx.num_cus * 8;
+  fork_streams(ctx);
   for (size_t ci = 0; ci < nc; ++ci) {
+    const hipStream_t cstream = ctx.aux[ci % Context::kAuxStreams];
     ColumnWork& w = work[ci];
     if (hs[ci].err) malformed(std::string(hs[ci].err == PQ_ERR_LEVELS ? "definition levels" : "values") + " of column '" + w.schema->name + "' are malformed");
     Column o;
@@ -220,7 +254,7 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
     const int32_t* row_val = (w.has_levels && o.null_count > 0) ? (const int32_t*)w.row_val->ptr : nullptr;
     if (rows == 0) {
       auto vb = make_device_buffer(64, ctx.device);
-      check_hip(hipMemsetAsync(vb->ptr, 0, 64, ctx.stream), "memset");
+      check_hip(hipMemsetAsync(vb->ptr, 0, 64, cstream), "memset");
       o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
       if (w.byte_array) { auto db = make_device_buffer(64, ctx.device); o.data = (const uint8_t*)db->ptr; o.owned.push_back(db); o.data_bytes = 0; }
       out.cols.push_back(std::move(o));
@@ -230,7 +264,7 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       auto vb = make_device_buffer((size_t)((rows + 63) / 64) * 8 + 16, ctx.device);
       PqRowParams r{};
       r.n_rows = rows; r.dense = (const uint8_t*)w.valid8->ptr; r.out = vb->ptr;
-      check_hip(pq_launch_pack_bits(r, grid, ctx.stream), "launch pq_pack_bits_kernel");
+      check_hip(pq_launch_pack_bits(r, grid, cstream), "launch pq_pack_bits_kernel");
       o.validity = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
     }
     if (w.byte_array) {
@@ -240,26 +274,27 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       PqRowParams r{};
       r.n_rows = rows; r.row_val = row_val; r.vsrc = (const uint32_t*)w.vsrc->ptr; r.vlen = (const uint32_t*)w.vlen->ptr;
       r.chunk = (const uint8_t*)w.chunkb->ptr; r.offsets = w.offsets->ptr; r.data_out = (uint8_t*)db->ptr;
-      check_hip(pq_launch_utf8_copy(r, grid, ctx.stream), "launch pq_utf8_copy_kernel");
+      check_hip(pq_launch_utf8_copy(r, grid, cstream), "launch pq_utf8_copy_kernel");
       o.values = (const uint8_t*)w.offsets->ptr; o.owned.push_back(w.offsets);
       o.data = (const uint8_t*)db->ptr; o.owned.push_back(db); o.data_bytes = (int64_t)total;
     } else if (w.boolean) {
       auto vb = make_device_buffer((size_t)((rows + 63) / 64) * 8 + 16, ctx.device);
       PqRowParams r{};
       r.n_rows = rows; r.row_val = row_val; r.dense = (const uint8_t*)w.dense->ptr; r.out = vb->ptr;
-      check_hip(pq_launch_pack_bits(r, grid, ctx.stream), "launch pq_pack_bits_kernel");
+      check_hip(pq_launch_pack_bits(r, grid, cstream), "launch pq_pack_bits_kernel");
       o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
     } else if (row_val) {
       auto vb = make_device_buffer((size_t)rows * w.width + 64, ctx.device);
       PqRowParams r{};
       r.n_rows = rows; r.row_val = row_val; r.dense = (const uint8_t*)w.dense->ptr; r.out = vb->ptr;
-      check_hip(pq_launch_gather_fixed(r, w.width, grid, ctx.stream), "launch pq_gather_fixed_kernel");
+      check_hip(pq_launch_gather_fixed(r, w.width, grid, cstream), "launch pq_gather_fixed_kernel");
       o.values = (const uint8_t*)vb->ptr; o.owned.push_back(vb);
     } else {   // no nulls: the dense values ARE the column
       o.values = (const uint8_t*)w.dense->ptr; o.owned.push_back(w.dense);
     }
     out.cols.push_back(std::move(o));
   }
+  join_streams(ctx);
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the temporaries of `work` are released on return
   return out;
 }
