@@ -232,11 +232,15 @@ __global__ __launch_bounds__(PQ_HYB_BLOCK) void pq_bool_rle_kernel(const PqDecod
 // SPECULATIVE: with L the length found at the current position, lane l looks at position + l * (4 + L) and checks that
 // the length prefix there is L too; the lanes up to the first disagreement are confirmed together (each one's position
 // follows from its predecessor's length).  Columns of equal-length strings (keys, codes, hashes, the reference's sample
-// data) advance 64 values per step, ragged ones at least one.
+// data) advance 256 values per step (four positions per lane), ragged ones at least one.
 constexpr int PQ_WALK_WINDOW = 32768;   // bytes
-__global__ __launch_bounds__(64) void pq_ba_walk_kernel(const PqDecodeParams p) {
-  __shared__ uint32_t s_win[PQ_WALK_WINDOW / 4 + 2];
-  const int lane = threadIdx.x;
+constexpr int PQ_WALK_SPEC = 4;         // speculative positions per lane and step
+constexpr int PQ_WALK_BLOCK = 256;      // all four waves stage the window (8 x 16 bytes per thread, in flight together); wave 0 walks
+__global__ __launch_bounds__(PQ_WALK_BLOCK) void pq_ba_walk_kernel(const PqDecodeParams p) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[PQ_WALK_WINDOW / 4 + 8];
+  __shared__ uint32_t s_state[3];   // next position, values found so far, malformed
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool walker = tid < 64;
   uint32_t values_at, values_len, n; uint32_t* osrc; uint32_t* olen;
   if (p.walk_dictionary) {
     values_at = p.dict_at; values_len = p.dict_len; n = p.dict_count; osrc = p.dict_src; olen = p.dict_len_out;
@@ -250,33 +254,56 @@ __global__ __launch_bounds__(64) void pq_ba_walk_kernel(const PqDecodeParams p) 
   uint32_t q = values_at, k = 0;
   bool failed = false;
   while (k < n && !failed) {
-    // stage [wbase, wbase + wbytes): wbase is q rounded down to a multiple of 4 (dword loads of the chunk buffer)
-    const uint32_t wbase = q & ~3u;
-    const uint32_t* g = (const uint32_t*)(p.chunk + wbase);
+    // stage [wbase, wbase + wbytes): wbase is q rounded down to a multiple of 16 (dwordx4 loads of the chunk buffer)
+    const uint32_t wbase = q & ~15u;
+    const uint4* g = (const uint4*)(p.chunk + wbase);
     const uint32_t wbytes = end - wbase < (uint32_t)PQ_WALK_WINDOW ? end - wbase : (uint32_t)PQ_WALK_WINDOW;
-    for (uint32_t i = lane; i < (wbytes + 3) / 4 + 1; i += 64) s_win[i] = g[i];   // (the chunk buffer is padded by 64 bytes)
+    const uint32_t nvec = (wbytes + 15) / 16 + 1;   // (the chunk buffer is padded by 64 bytes)
+    uint4 stage[PQ_WALK_WINDOW / 16 / PQ_WALK_BLOCK + 1];
+#pragma unroll
+    for (int u = 0; u < PQ_WALK_WINDOW / 16 / PQ_WALK_BLOCK + 1; ++u) { const uint32_t i = u * PQ_WALK_BLOCK + tid; if (i < nvec) stage[u] = g[i]; }
+#pragma unroll
+    for (int u = 0; u < PQ_WALK_WINDOW / 16 / PQ_WALK_BLOCK + 1; ++u) { const uint32_t i = u * PQ_WALK_BLOCK + tid; if (i < nvec) ((uint4*)s_win)[i] = stage[u]; }
     __syncthreads();
-    auto length_at = [&](uint32_t pos) {   // pos + 4 <= wbase + wbytes
-      const uint32_t off = pos - wbase;
-      return (uint32_t)__builtin_amdgcn_alignbyte(s_win[(off >> 2) + 1], s_win[off >> 2], off & 3);
-    };
-    while (k < n) {
-      if (q + 4 > end) { failed = true; break; }
-      if (q + 4 > wbase + wbytes) break;                       // the next length prefix lies outside the window: restage
-      const uint32_t L = length_at(q);                          // (uniform)
-      if (L > end - q - 4) { failed = true; break; }
-      const uint64_t c = (uint64_t)q + (uint64_t)lane * (4ull + L);
-      bool ok = k + lane < n && c + 4 <= (uint64_t)wbase + wbytes && c + 4 + L <= end;
-      if (ok) ok = length_at((uint32_t)c) == L;
-      const unsigned long long m = __ballot(ok);
-      const int cnt = m == ~0ull ? 64 : __builtin_ctzll(~m);   // lane 0 always agrees with itself: cnt >= 1
-      if (lane < cnt) { osrc[k + lane] = (uint32_t)c + 4; olen[k + lane] = L; }
-      k += (uint32_t)cnt;
-      q += (uint32_t)cnt * (4u + L);
+    if (walker) {
+      auto length_at = [&](uint32_t pos) {   // pos + 4 <= wbase + wbytes
+        const uint32_t off = pos - wbase;
+        return (uint32_t)__builtin_amdgcn_alignbyte(s_win[(off >> 2) + 1], s_win[off >> 2], off & 3);
+      };
+      while (k < n) {
+        if (q + 4 > end) { failed = true; break; }
+        if (q + 4 > wbase + wbytes) break;                       // the next length prefix lies outside the window: restage
+        const uint32_t L = length_at(q);                          // (uniform)
+        if (L > end - q - 4) { failed = true; break; }
+        // four positions per lane (256 per step): all four LDS reads are issued before the first ballot
+        unsigned long long m[PQ_WALK_SPEC];
+        uint32_t cpos[PQ_WALK_SPEC];
+#pragma unroll
+        for (int j = 0; j < PQ_WALK_SPEC; ++j) {
+          const uint64_t c = (uint64_t)q + (uint64_t)(j * 64 + lane) * (4ull + L);
+          bool ok = (uint64_t)k + j * 64 + lane < n && c + 4 <= (uint64_t)wbase + wbytes && c + 4 + L <= end;
+          if (ok) ok = length_at((uint32_t)c) == L;
+          m[j] = __ballot(ok);
+          cpos[j] = (uint32_t)c + 4;
+        }
+        uint32_t total = 0;   // lane 0 of the first batch always agrees with itself: total >= 1
+#pragma unroll
+        for (int j = 0; j < PQ_WALK_SPEC; ++j) {
+          const int cnt = m[j] == ~0ull ? 64 : __builtin_ctzll(~m[j]);
+          if (lane < cnt) { osrc[k + total + lane] = cpos[j]; olen[k + total + lane] = L; }
+          total += (uint32_t)cnt;
+          if (cnt < 64) break;
+        }
+        k += total;
+        q += total * (4u + L);
+      }
+      if (lane == 0) { s_state[0] = q; s_state[1] = k; s_state[2] = failed; }
     }
     __syncthreads();
+    q = s_state[0]; k = s_state[1]; failed = s_state[2] != 0;
+    __syncthreads();
   }
-  if (failed) {   // malformed page: the rest reads as empty strings
+  if (failed && walker) {   // malformed page: the rest reads as empty strings
     if (lane == 0) flag_error(p.err, PQ_ERR_VALUES);
     for (uint32_t i = k + lane; i < n; i += 64) { osrc[i] = values_at; olen[i] = 0; }
   }
@@ -432,7 +459,7 @@ hipError_t pq_launch_dict_fixed(const PqDecodeParams& p, int n_list, hipStream_t
 }
 hipError_t pq_launch_bool(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_kernel, dim3(n_list), dim3(256), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_bool_rle(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_bool_rle_kernel, dim3(n_list), dim3(PQ_HYB_BLOCK), 0, s, p); return hipGetLastError(); }
-hipError_t pq_launch_ba_walk(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_ba_walk_kernel, dim3(n_list), dim3(64), 0, s, p); return hipGetLastError(); }
+hipError_t pq_launch_ba_walk(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_ba_walk_kernel, dim3(n_list), dim3(PQ_WALK_BLOCK), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_dict_ba(const PqDecodeParams& p, int n_list, hipStream_t s) { hipLaunchKernelGGL(pq_dict_ba_kernel, dim3(n_list), dim3(PQ_HYB_BLOCK), 0, s, p); return hipGetLastError(); }
 hipError_t pq_launch_gather_fixed(const PqRowParams& p, int width, int grid, hipStream_t s) {
   switch (width) {
