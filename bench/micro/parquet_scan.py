@@ -53,3 +53,30 @@ for it in range(4):
     g.close()
     best = min(best, t2 - t1); best_open = min(best_open, t1 - t0)
 print(f"chq scan (metadata {best_open * 1e3:.2f} ms + upload and GPU decode of every row group): {best * 1e3:.1f} ms = {len(raw) / best / 1e9:.2f} GB/s of file bytes, {n / best / 1e6:.1f} M rows/s")
+
+# ---- f-4: the same table written back: pyarrow's writer on the host vs pages encoded on the GPU ---------------------------
+m = min(n, 4_000_000)     # one row group / one page per column: keep every page below 2 GiB
+rec = t.slice(0, m).to_batches()[0]
+best = 1e9
+for _ in range(3):
+    sink = io.BytesIO()
+    t0 = time.perf_counter()
+    pq.write_table(pa.Table.from_batches([rec]), sink, compression="none")
+    best = min(best, time.perf_counter() - t0)
+print(f"pyarrow write_table ({m} rows, uncompressed, dictionary on): {best * 1e3:.1f} ms = {m / best / 1e6:.1f} M rows/s, {len(sink.getvalue()) / 1e6:.1f} MB")
+best = 1e9
+for _ in range(3):
+    sink = io.BytesIO()
+    t0 = time.perf_counter()
+    pq.write_table(pa.Table.from_batches([rec]), sink, compression="none", use_dictionary=False)
+    best = min(best, time.perf_counter() - t0)
+print(f"pyarrow write_table ({m} rows, uncompressed, PLAIN): {best * 1e3:.1f} ms = {m / best / 1e6:.1f} M rows/s")
+dev = chq.DeviceRecordBatch.from_host(rec, ctx=ctx)
+best = 1e9
+for it in range(4):
+    t0 = time.perf_counter()
+    image = chq.record_to_parquet(dev, ctx=ctx)
+    best = min(best, time.perf_counter() - t0)
+    if it == 0:
+        assert pq.read_table(io.BytesIO(image)).to_batches()[0].equals(rec)
+print(f"chq record_to_parquet from a device batch (file image in host memory, Python bytes copy included): {best * 1e3:.1f} ms = {m / best / 1e6:.1f} M rows/s, {len(image) / 1e6:.1f} MB")

@@ -69,6 +69,10 @@ IpcMessage._fields_ = [("header", C.c_void_p), ("header_len", C.c_int64), ("body
                        ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
+class ParquetImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_int64), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
 class CallStats(C.Structure):
     _fields_ = [("rows_in", C.c_int64), ("rows_out", C.c_int64), ("tiles", C.c_int64), ("launches", C.c_int64),
                 ("bytes_read_alg", C.c_int64), ("bytes_written_alg", C.c_int64), ("kernel_ns", C.c_int64)]
@@ -83,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
     "chq_record_copy_to_peer", "chq_record_to_ipc", "chq_record_from_ipc", "chq_ipc_describe",
     "chq_parquet_open", "chq_parquet_close", "chq_parquet_num_row_groups", "chq_parquet_row_group_num_rows",
-    "chq_parquet_describe", "chq_parquet_read_row_group",
+    "chq_parquet_describe", "chq_parquet_read_row_group", "chq_record_to_parquet",
 ]
 
 
@@ -162,6 +166,7 @@ def lib():
         "chq_parquet_row_group_num_rows": (i64, [vp, C.c_int32]),
         "chq_parquet_describe": (ci, [vp, C.c_char_p, C.c_size_t]),
         "chq_parquet_read_row_group": (ci, [vp, vp, C.c_int32, ci, PDA, PS]),
+        "chq_record_to_parquet": (ci, [vp, PDA, PS, C.POINTER(ParquetImage)]),
     }
     for name, (res, args) in sig.items():
         try:

@@ -488,6 +488,29 @@ chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32
   });
 }
 
+namespace {
+struct ParquetImageHolder { chq::ParquetImage img; };
+void release_parquet_image(chq_parquet_image* m) {
+  if (!m || !m->release) return;
+  delete (ParquetImageHolder*)m->private_data;
+  m->data = nullptr; m->len = 0; m->private_data = nullptr; m->release = nullptr;
+}
+}  // namespace
+
+chq_status chq_record_to_parquet(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, chq_parquet_image* out) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  if (out) { out->data = nullptr; out->len = 0; out->release = nullptr; out->private_data = nullptr; }
+  return guarded(ctx, [&] {
+    require(out, "output image");
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    Batch in = import_batch(rec, schema);
+    auto* h = new ParquetImageHolder();
+    try { h->img = record_to_parquet(ctx->c, in); } catch (...) { delete h; throw; }
+    out->data = (const uint8_t*)h->img.bytes->ptr; out->len = h->img.len;
+    out->release = release_parquet_image; out->private_data = h;
+  });
+}
+
 chq_status chq_record_to_host(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, ArrowDeviceArray* out,
                               ArrowSchema* out_schema) {
   if (!ctx) return CHQ_ERR_INVALID_HANDLE;

@@ -12,6 +12,7 @@
 // create_sample_data.rs:222, materialize_files_task.rs:128-133).  Anything else: CHQ_ERR_NOT_SUPPORTED with the reason.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -81,7 +82,15 @@ std::string parquet_describe(const PqFile& f);
 
 struct Context;
 struct Batch;
+struct Buffer;
 // One row group decoded into a device-resident batch (parquet_scan.cpp + parquet.hip).
 Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group);
+
+// One record batch -> one complete Parquet file (one row group) in host memory (parquet_write.cpp + parquet_write.hip).
+struct ParquetImage {
+  std::shared_ptr<Buffer> bytes;   // host memory
+  int64_t len = 0;
+};
+ParquetImage record_to_parquet(Context& ctx, const Batch& rec);
 
 }  // namespace chq

@@ -69,4 +69,27 @@ hipError_t pq_launch_rowlen(const PqRowParams& p, hipStream_t s);
 hipError_t pq_launch_utf8_copy(const PqRowParams& p, int grid, hipStream_t s);
 constexpr int PQ_SCAN_ROWS_HOST = 4096;   // = PQ_SCAN_ROWS of parquet.hip
 
+// ---- Parquet write (parquet_write.hip) -------------------------------------------------------------------------------
+struct PwParams {
+  int64_t n_rows;
+  const uint8_t* validity;      // Arrow validity bitmap or null (all valid)
+  int64_t bit_offset;           // of row 0 in `validity`
+  const uint8_t* values;        // fixed-width: values at row 0; bits_to_bytes: the Boolean bitmap; bytes_to_bits: one byte per value
+  int64_t value_bit_offset;     // bits_to_bytes: of row 0 in `values`
+  const int32_t* offsets;       // Utf8: offsets at row 0 (null for fixed-width columns)
+  const uint8_t* data;          // Utf8: bytes (absolute offsets)
+  int32_t width;                // fixed-width: bytes per value
+  int32_t pad;
+  uint8_t* out;
+  unsigned long long* block_sums;   // [n_blocks]
+  int64_t n_blocks;                 // ceil(n_rows / PW_BLOCK_ROWS_HOST)
+  unsigned long long* total_bytes;
+};
+constexpr int PW_BLOCK_ROWS_HOST = 4096;   // = PW_BLOCK_ROWS of parquet_write.hip
+hipError_t pw_launch_scan(const PwParams& p, hipStream_t s);
+hipError_t pw_launch_encode(const PwParams& p, hipStream_t s);
+hipError_t pw_launch_bits_to_bytes(const PwParams& p, int grid, hipStream_t s);
+hipError_t pw_launch_bytes_to_bits(const PwParams& p, int grid, hipStream_t s);
+hipError_t pw_launch_shift_bits(const PwParams& p, int grid, hipStream_t s);
+
 }  // namespace chq

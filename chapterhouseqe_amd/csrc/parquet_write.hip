@@ -1,0 +1,157 @@
+// parquet_write.hip -- gfx950 kernels that turn Arrow columns in HBM into the PLAIN-encoded value streams of Parquet data
+// pages (the step behind the projection: materialize_files_task.rs:128-141 in the reference,
+// where the `parquet` crate encodes on the CPU).  The host (parquet_write.cpp) writes page headers and the footer and
+// copies the streams into the file image.
+//   non-null fixed-width columns need no kernel at all: the Arrow values buffer IS the PLAIN stream;
+//   definition levels are the Arrow validity bitmap behind a one-run header (bit width 1, LSB first: the same bit order);
+//   pw_counts_kernel / pw_scan_kernel   per-block totals of "bytes this row contributes" and their exclusive scan
+//   pw_compact_fixed_kernel             values of the non-null rows, densely packed
+//   pw_utf8_encode_kernel               [4-byte length][bytes] per non-null row
+//   pw_bits_to_bytes_kernel             Boolean bitmap (any bit offset) -> one byte per row (then compacted and re-packed)
+// Memory-bound byte work: no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "parquet_device.h"
+
+namespace chq {
+
+namespace {
+constexpr int PW_BLOCK_ROWS = 4096;
+
+__device__ __forceinline__ bool row_valid(const PwParams& p, int64_t r) {
+  if (!p.validity) return true;
+  const int64_t b = p.bit_offset + r;
+  return (p.validity[b >> 3] >> (b & 7)) & 1;
+}
+// bytes row r contributes to the value stream
+__device__ __forceinline__ uint32_t row_bytes(const PwParams& p, int64_t r) {
+  if (r >= p.n_rows || !row_valid(p, r)) return 0;
+  if (p.offsets) return 4u + (uint32_t)(p.offsets[r + 1] - p.offsets[r]);
+  return (uint32_t)p.width;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void pw_counts_kernel(const PwParams p) {
+  __shared__ unsigned long long s_w[4];
+  const int64_t r0 = (int64_t)blockIdx.x * PW_BLOCK_ROWS;
+  unsigned long long s = 0;
+  for (int i = threadIdx.x; i < PW_BLOCK_ROWS; i += 256) s += row_bytes(p, r0 + i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) p.block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(256) void pw_scan_kernel(const PwParams p) {
+  __shared__ unsigned long long s_part[256];
+  __shared__ unsigned long long s_carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < p.n_blocks; base += 256) {
+    const int64_t i = base + tid;
+    const unsigned long long v = i < p.n_blocks ? p.block_sums[i] : 0ull;
+    s_part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const unsigned long long t = tid >= o ? s_part[tid - o] : 0ull;
+      __syncthreads();
+      s_part[tid] += t;
+      __syncthreads();
+    }
+    if (i < p.n_blocks) p.block_sums[i] = s_carry + s_part[tid] - v;
+    __syncthreads();
+    if (tid == 255) s_carry += s_part[255];
+    __syncthreads();
+  }
+  if (tid == 0) *p.total_bytes = s_carry;
+}
+
+// One block per PW_BLOCK_ROWS rows; 256 rows per step, positions from a block-local scan on top of the block's base.
+// Fixed-width: out[pos] = value; Utf8: out[pos] = length, bytes behind it.
+template <int W>
+__global__ __launch_bounds__(256) void pw_encode_kernel(const PwParams p) {
+  __shared__ uint32_t s_wave[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * PW_BLOCK_ROWS;
+  unsigned long long run = p.block_sums[blockIdx.x];
+  for (int step = 0; step < PW_BLOCK_ROWS; step += 256) {
+    const int64_t r = r0 + step + tid;
+    const uint32_t nb = row_bytes(p, r);
+    uint32_t inc = nb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wv; ++w) before += s_wave[w];
+    const uint32_t all = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (nb) {
+      uint8_t* dst = p.out + run + before + inc - nb;
+      if (W > 0) {
+        const uint8_t* src = p.values + r * W;
+#pragma unroll
+        for (int b = 0; b < W; ++b) dst[b] = src[b];          // (the stream is only byte aligned)
+      } else {
+        const uint32_t len = nb - 4;
+        __builtin_memcpy(dst, &len, 4);
+        const uint8_t* src = p.data + p.offsets[r];
+        for (uint32_t b = 0; b < len; ++b) dst[4 + b] = src[b];
+      }
+    }
+    run += all;
+    __syncthreads();
+  }
+}
+
+// Boolean values (bitmap at bit offset `value_bit_offset`) -> one byte per row
+__global__ __launch_bounds__(256) void pw_bits_to_bytes_kernel(const PwParams p) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p.n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = p.value_bit_offset + r;
+    p.out[r] = (p.values[b >> 3] >> (b & 7)) & 1;
+  }
+}
+// one byte per value -> bit-packed, LSB first (PLAIN BOOLEAN); n_rows = number of values
+__global__ __launch_bounds__(256) void pw_bytes_to_bits_kernel(const PwParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (p.n_rows + 63) >> 6;
+  for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwords; w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t r = (w << 6) + lane;
+    const unsigned long long m = __ballot(r < p.n_rows && p.values[r] != 0);
+    if (lane == 0) ((unsigned long long*)p.out)[w] = m;
+  }
+}
+// validity bitmap at a bit offset -> the same bits from bit 0 (definition levels of a sliced column); n_rows bits
+__global__ __launch_bounds__(256) void pw_shift_bits_kernel(const PwParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (p.n_rows + 63) >> 6;
+  for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwords; w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+    const int64_t r = (w << 6) + lane;
+    const unsigned long long m = __ballot(r < p.n_rows && row_valid(p, r));
+    if (lane == 0) ((unsigned long long*)p.out)[w] = m;
+  }
+}
+
+hipError_t pw_launch_scan(const PwParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(pw_counts_kernel, dim3((unsigned)p.n_blocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(pw_scan_kernel, dim3(1), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+hipError_t pw_launch_encode(const PwParams& p, hipStream_t s) {
+  const dim3 g((unsigned)p.n_blocks), b(256);
+  if (p.offsets) hipLaunchKernelGGL(pw_encode_kernel<0>, g, b, 0, s, p);
+  else switch (p.width) {
+    case 1: hipLaunchKernelGGL(pw_encode_kernel<1>, g, b, 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pw_encode_kernel<4>, g, b, 0, s, p); break;
+    case 8: hipLaunchKernelGGL(pw_encode_kernel<8>, g, b, 0, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t pw_launch_bits_to_bytes(const PwParams& p, int grid, hipStream_t s) { hipLaunchKernelGGL(pw_bits_to_bytes_kernel, dim3(grid), dim3(256), 0, s, p); return hipGetLastError(); }
+hipError_t pw_launch_bytes_to_bits(const PwParams& p, int grid, hipStream_t s) { hipLaunchKernelGGL(pw_bytes_to_bits_kernel, dim3(grid), dim3(256), 0, s, p); return hipGetLastError(); }
+hipError_t pw_launch_shift_bits(const PwParams& p, int grid, hipStream_t s) { hipLaunchKernelGGL(pw_shift_bits_kernel, dim3(grid), dim3(256), 0, s, p); return hipGetLastError(); }
+
+}  // namespace chq

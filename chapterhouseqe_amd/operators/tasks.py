@@ -234,27 +234,42 @@ class MaterializeFilesTask:
             return self._project(self.materialize_file_config.fields, rec, aliases)
         if self._ctx is None:
             self._ctx = record_utils.Context(self.operator_instance_config.device_id)
-        return record_utils.project_record(self.materialize_file_config.fields, rec, aliases, ctx=self._ctx, device_result=False)
+        # the projected batch stays in HBM: the Parquet pages are encoded there too
+        return record_utils.project_record(self.materialize_file_config.fields, rec, aliases, ctx=self._ctx, device_result=True)
+
+    def _write_parquet(self, proj_rec, path: str) -> None:
+        """materialize_files_task.rs:128-141 (AsyncArrowWriter ... write ... close).  A device-resident result is encoded on
+        the GPU (`chq_record_to_parquet`) and only the finished file image reaches the host; column types that encoder does
+        not write (and the oracle-driven CPU tests, whose batches never were on a device) go through pyarrow's writer."""
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+        if isinstance(proj_rec, record_utils.DeviceRecordBatch):
+            try:
+                image = record_utils.record_to_parquet(proj_rec, ctx=self._ctx)
+            except record_utils.ChqError as e:
+                if e.code != 30:   # NotSupported: a type outside Int32/Int64/Float32/Float64/Boolean/Utf8
+                    raise
+                proj_rec = proj_rec.to_host()
+            else:
+                with open(path, "wb") as f:
+                    f.write(image)
+                return
+        pq.write_table(pa.Table.from_batches([proj_rec]), path)
 
     def async_main(self) -> None:
-        """materialize_files_task.rs:68-170: pull -> project -> write /query_results/<uuid>/rec_<id>.parquet -> ack.
-        (The parquet encode itself is outside the hot path; pyarrow writes it.)"""
-        import pyarrow.parquet as pq
+        """materialize_files_task.rs:68-170: pull -> project -> write /query_results/<uuid>/rec_<id>.parquet -> ack."""
         rec_handler = RecordHandler.initiate(self.operator_instance_config, self.inbound_exchanges, self.outbound_exchange)
         query_uuid = uuid.UUID(int=self.operator_instance_config.query_id)
         out_dir = os.path.join(self.storage_root, "query_results", str(query_uuid))
         os.makedirs(out_dir, exist_ok=True)
-        import pyarrow as pa
         try:
             while True:
                 exchange_rec = rec_handler.next_record()
                 if exchange_rec is None:
                     break
                 proj_rec = self._project_record(exchange_rec.record, exchange_rec.table_aliases)
-                if hasattr(proj_rec, "to_host"):
-                    proj_rec = proj_rec.to_host()
                 path = os.path.join(out_dir, f"rec_{exchange_rec.record_id}.parquet")
-                pq.write_table(pa.Table.from_batches([proj_rec]), path)
+                self._write_parquet(proj_rec, path)
                 self.files_written.append(path)
                 rec_handler.complete_record(exchange_rec)
         finally:

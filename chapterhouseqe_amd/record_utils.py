@@ -496,6 +496,24 @@ class ParquetFile:
             pass
 
 
+def record_to_parquet(record: Record, *, ctx: Optional[Context] = None) -> bytes:
+    """One record batch (host or device resident) -> the bytes of one Parquet file with one row group, pages encoded on the
+    GPU (`chq_record_to_parquet`; what materialize_files_task.rs:128-141 does with the parquet crate on the CPU)."""
+    ctx, src, own_src, _ = _prepare(record, ctx)
+    img = L.ParquetImage()
+    try:
+        rc = L.lib().chq_record_to_parquet(ctx.handle, C.byref(src.array), C.byref(src.schema), C.byref(img))
+    finally:
+        if own_src:
+            src.release()
+    if rc:
+        raise ChqError(rc, ctx.last_error())
+    try:
+        return C.string_at(img.data, img.len)
+    finally:
+        C.CFUNCTYPE(None, C.c_void_p)(img.release)(C.addressof(img))
+
+
 def scan_parquet(source, *, ctx: Optional[Context] = None, device_result: bool = True):
     """Every row group of a Parquet file as one batch each, decoded on the GPU (generator)."""
     f = ParquetFile(source)

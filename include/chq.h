@@ -288,6 +288,24 @@ chq_status chq_parquet_describe(const chq_parquet* pq, char* buf, size_t buf_len
 chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32_t row_group, int out_device,
                                       struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
 
+/* ---- Parquet write with the page encode on the GPU ---------------------------------------
+ * Replaces the encode the reference does with the `parquet` crate behind project_record
+ * (operators/materialize_tasks/materialize_files_task.rs:128-141: AsyncArrowWriter::try_new(writer, schema, None),
+ * write(&rec), close() -- one file with one row group per record).  `rec` (host or device resident) becomes one complete
+ * Parquet file image in host memory, ready for the storage writer: the value streams of the pages are produced in HBM and
+ * copied once into place, headers and footer are written on the host.  Format: PLAIN, UNCOMPRESSED, data pages V1, one
+ * page per column, definition levels = the Arrow validity bitmap.  Every Parquet reader decodes it; it is not
+ * byte-identical to the parquet crate's output (which dictionary-encodes and adds min/max statistics).
+ * Types: Int32, Int64, Float32, Float64, Boolean, Utf8; others CHQ_ERR_NOT_SUPPORTED. */
+typedef struct chq_parquet_image {
+  const uint8_t* data;   /* host memory, `len` bytes: "PAR1" ... footer ... "PAR1" */
+  int64_t len;
+  void (*release)(struct chq_parquet_image*);
+  void* private_data;
+} chq_parquet_image;
+chq_status chq_record_to_parquet(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
+                                 chq_parquet_image* out);
+
 /* Wrap caller-owned device (or host) buffers as a record batch without copying; the buffers must
  * outlive the returned structs, whose release callbacks free only the descriptors. `format` is an
  * Arrow C format string ("i","f","g","l","b","u", ...). */

@@ -89,6 +89,15 @@ pub struct chq_ipc_message {
     pub private_data: *mut c_void,
 }
 
+/// struct chq_parquet_image: a complete Parquet file in host memory
+#[repr(C)]
+pub struct chq_parquet_image {
+    pub data: *const u8,
+    pub len: i64,
+    pub release: Option<unsafe extern "C" fn(*mut chq_parquet_image)>,
+    pub private_data: *mut c_void,
+}
+
 // Every function include/chq.h declares, in header order (tests/test_abi.py checks names and arity against the header).
 #[link(name = "chq")]
 extern "C" {
@@ -190,6 +199,10 @@ extern "C" {
     pub fn chq_parquet_read_row_group(
         ctx: *mut chq_ctx, pq: *const chq_parquet, row_group: i32, out_device: c_int,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
+    ) -> c_int;
+    /// one record batch -> one Parquet file image in host memory, pages encoded on the GPU (materialize_files_task.rs:128-141)
+    pub fn chq_record_to_parquet(
+        ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema, out: *mut chq_parquet_image,
     ) -> c_int;
     pub fn chq_wrap_columns(
         ctx: *mut chq_ctx, cols: *const chq_column_desc, n_cols: c_int, n_rows: i64, device_type: c_int,

@@ -120,3 +120,71 @@ def test_unsupported_features_say_so(ctx):
     assert e.value.code == 30 and "encoding" in str(e.value)
     with pytest.raises(chq.ChqError):
         chq.ParquetFile(write_bytes(t)).read_row_group(5, ctx=ctx)
+
+
+# ---- f-4: pages encoded on the GPU ---------------------------------------------------------------------------------------
+def write_table_cases():
+    rng = np.random.default_rng(21)
+    for n in [0, 1, 7, 8, 9, 63, 64, 65, 1000, 4095, 4096, 4097, 50_000]:
+        for nulls in (False, True):
+            yield sample_table(n, seed=n + 100, nulls=nulls, strings="mixed")
+    n = 10_000   # the reference's batch size and schema, non-nullable fields
+    schema = pa.schema([pa.field("id", pa.int32(), nullable=False), pa.field("value1", pa.utf8(), nullable=False),
+                        pa.field("value2", pa.float32(), nullable=False)])
+    yield pa.table([pa.array(np.arange(n, dtype=np.int32)), pa.array(["%08x" % v for v in rng.integers(0, 2**32, n)]),
+                    pa.array((rng.random(n) * 100).astype(np.float32))], schema=schema)
+
+
+def test_written_files_are_read_back_by_pyarrow_and_by_the_scan(ctx):
+    for t in write_table_cases():
+        rec = t.to_batches()[0] if t.num_rows else pa.RecordBatch.from_arrays([pa.array([], type=f.type) for f in t.schema], schema=t.schema)
+        for source in (rec, chq.DeviceRecordBatch.from_host(rec, ctx=ctx)):
+            raw = chq.record_to_parquet(source, ctx=ctx)
+            back = pq.read_table(io.BytesIO(raw))
+            assert back.schema.names == rec.schema.names and back.num_rows == rec.num_rows
+            md = pq.ParquetFile(io.BytesIO(raw)).metadata
+            assert md.num_row_groups == 1 and md.row_group(0).num_rows == rec.num_rows
+            for i, f in enumerate(rec.schema):
+                got = back.column(i).combine_chunks()
+                assert got.type == f.type and got.null_count == rec.column(i).null_count, f.name
+                assert got.equals(rec.column(i)), f.name
+                assert back.schema.field(i).nullable == f.nullable
+            # ... and by this library's own scan (f-3 reads what f-4 writes)
+            mine = chq.ParquetFile(raw).read_row_group(0, ctx=ctx).to_host()
+            assert mine.equals(rec)
+
+
+def test_sliced_batches_are_written_from_their_first_row(ctx):
+    t = sample_table(5000, seed=77, nulls=True)
+    for off, ln in [(1, 100), (3, 4000), (64, 4936), (4097, 500)]:
+        rec = t.slice(off, ln).to_batches()[0]
+        for source in (rec, chq.DeviceRecordBatch.from_host(rec, ctx=ctx)):
+            back = pq.read_table(io.BytesIO(chq.record_to_parquet(source, ctx=ctx)))
+            assert back.to_batches()[0].equals(rec) if ln else back.num_rows == 0
+
+
+def test_filter_project_write_stays_on_the_device_until_the_file_image(ctx):
+    """scan -> filter -> project -> write: the reference's whole query DAG for simple.sql, host memory only at both ends"""
+    n = 30_000
+    rng = np.random.default_rng(31)
+    t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "value1": pa.array(["%08x" % v for v in rng.integers(0, 2**32, n)]),
+                  "value2": pa.array((rng.random(n) * 100).astype(np.float32))})
+    raw_in = write_bytes(t)
+    from chapterhouseqe_amd.sqlparse import parse_select
+    items = parse_select("select id, value2 * 2.0 as twice, value1 from t").projection
+    dev = chq.ParquetFile(raw_in).read_row_group(0, ctx=ctx)
+    al = chq.get_record_table_aliases(None, dev)
+    e = parse_expr("value2 > 50.0")
+    kept = chq.filter_record(dev, al, e, ctx=ctx)
+    proj = chq.project_record(items, kept, al, ctx=ctx)
+    got = pq.read_table(io.BytesIO(chq.record_to_parquet(proj, ctx=ctx))).to_batches()[0]
+    host = t.to_batches()[0]
+    exp = O.project_record(items, O.filter_record(host, al, e), al)
+    assert got.equals(exp)
+
+
+def test_unsupported_types_for_writing_say_so(ctx):
+    rec = pa.record_batch({"d": pa.array([1, 2, 3], type=pa.date32())})
+    with pytest.raises(chq.ChqError) as e:
+        chq.record_to_parquet(rec, ctx=ctx)
+    assert e.value.code == 30 and "date" in str(e.value).lower() or "tdD" in str(e.value)
