@@ -78,5 +78,5 @@ for it in range(4):
     image = chq.record_to_parquet(dev, ctx=ctx)
     best = min(best, time.perf_counter() - t0)
     if it == 0:
-        assert pq.read_table(io.BytesIO(image)).to_batches()[0].equals(rec)
+        assert pq.read_table(io.BytesIO(image)).combine_chunks().equals(pa.Table.from_batches([rec]))
 print(f"chq record_to_parquet from a device batch (file image in host memory, Python bytes copy included): {best * 1e3:.1f} ms = {m / best / 1e6:.1f} M rows/s, {len(image) / 1e6:.1f} MB")
