@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void pw_scan_kernel(const PwParams p) {
 template <int W>
 __global__ __launch_bounds__(256) void pw_encode_kernel(const PwParams p) {
   __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_dst[256], s_len[256];   // Utf8: where each row of the step goes, how long it is (~0: nothing to write)
+  __shared__ int32_t s_src[256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * PW_BLOCK_ROWS;
   unsigned long long run = p.block_sums[blockIdx.x];
@@ -88,17 +90,30 @@ __global__ __launch_bounds__(256) void pw_encode_kernel(const PwParams p) {
     uint32_t before = 0;
     for (int w = 0; w < wv; ++w) before += s_wave[w];
     const uint32_t all = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    if (nb) {
-      uint8_t* dst = p.out + run + before + inc - nb;
-      if (W > 0) {
+    if (W > 0) {
+      if (nb) {
+        uint8_t* dst = p.out + run + before + inc - nb;
         const uint8_t* src = p.values + r * W;
 #pragma unroll
         for (int b = 0; b < W; ++b) dst[b] = src[b];          // (the stream is only byte aligned)
-      } else {
-        const uint32_t len = nb - 4;
-        __builtin_memcpy(dst, &len, 4);
-        const uint8_t* src = p.data + p.offsets[r];
-        for (uint32_t b = 0; b < len; ++b) dst[4 + b] = src[b];
+      }
+    } else {
+      // [4-byte length][bytes]: positions by one thread per row, the bytes by eight lanes per row in 16-byte chunks
+      s_dst[tid] = before + inc - nb;                          // relative to this step's first byte
+      s_len[tid] = nb ? nb - 4 : ~0u;
+      s_src[tid] = nb ? p.offsets[r] : 0;
+      __syncthreads();
+      uint8_t* base = p.out + run;
+      const int sl = tid & 7;
+      for (int row = tid >> 3; row < 256; row += 32) {
+        const uint32_t len = s_len[row];
+        if (len == ~0u) continue;
+        uint8_t* dst = base + s_dst[row];
+        const uint8_t* src = p.data + s_src[row];
+        if (sl == 0) __builtin_memcpy(dst, &len, 4);
+        uint32_t b = (uint32_t)sl * 16;
+        for (; b + 16 <= len; b += 128) { uint4 w; __builtin_memcpy(&w, src + b, 16); __builtin_memcpy(dst + 4 + b, &w, 16); }
+        for (uint32_t k = (len & ~15u) + sl; k < len; k += 8) dst[4 + k] = src[k];
       }
     }
     run += all;

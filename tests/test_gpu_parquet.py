@@ -188,3 +188,30 @@ def test_unsupported_types_for_writing_say_so(ctx):
     with pytest.raises(chq.ChqError) as e:
         chq.record_to_parquet(rec, ctx=ctx)
     assert e.value.code == 30 and "date" in str(e.value).lower() or "tdD" in str(e.value)
+
+
+def test_damaged_pages_are_reported_not_decoded_into_garbage_addresses(ctx):
+    """bytes of the value streams overwritten: dictionary indices beyond the dictionary, length prefixes beyond the page,
+    truncated level runs -- the kernels clamp every access to its page and the call reports the column"""
+    n = 20_000
+    rng = np.random.default_rng(41)
+    t = pa.table({"k": pa.array(rng.integers(0, 50, n).astype(np.int32)), "s": pa.array(["v%05d" % v for v in rng.integers(0, 99999, n)]),
+                  "o": pa.array(rng.integers(0, 9, n), type=pa.int64(), mask=rng.random(n) < 0.3)})
+    raw = write_bytes(t, data_page_size=4096)
+    md = pq.ParquetFile(io.BytesIO(raw)).metadata
+    reported = 0
+    for col in range(3):
+        cm = md.row_group(0).column(col)
+        start, size = cm.data_page_offset, cm.total_compressed_size
+        for frac in (0.1, 0.5, 0.9):
+            bad = bytearray(raw)
+            at = start + int(size * frac * 0.8)
+            bad[at:at + 64] = b"\xff" * 64
+            try:
+                f = chq.ParquetFile(bytes(bad))
+                got = f.read_row_group(0, ctx=ctx)
+                assert got.num_rows == n       # damage that still decodes (e.g. inside string bytes) is fine
+            except chq.ChqError as e:
+                assert e.code in (22, 30), str(e)
+                reported += 1
+    assert reported >= 3

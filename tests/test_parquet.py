@@ -87,3 +87,25 @@ def test_the_reference_sample_shape():
     assert [c[2] for c in cols] == ["INT32", "BYTE_ARRAY", "FLOAT"] and "utf8" in cols[1]
     encs = {p["enc"] for ch in rgs[0]["chunks"] for p in ch["pages"] if p["type"] == 0}
     assert encs == {0, 8}      # dictionary pages first, PLAIN after the dictionary outgrew its limit: both in one chunk
+
+
+def test_corrupted_metadata_never_crashes_the_reader():
+    """random byte damage inside the footer and the page headers: every outcome is either a parsed file or a ChqError"""
+    raw = bytearray(write_bytes(sample_table(3000, seed=4, nulls=True), data_page_size=1024))
+    footer_len = int.from_bytes(raw[-8:-4], "little")
+    rng = np.random.default_rng(12)
+    opened = failed = 0
+    for trial in range(400):
+        bad = bytearray(raw)
+        lo = len(raw) - 8 - footer_len if trial % 2 == 0 else 4
+        hi = len(raw) - 8 if trial % 2 == 0 else len(raw) - 8 - footer_len
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(lo, hi))] = int(rng.integers(0, 256))
+        try:
+            f = chq.ParquetFile(bytes(bad))
+            f.describe()
+            f.close()
+            opened += 1
+        except chq.ChqError:
+            failed += 1
+    assert opened + failed == 400 and failed > 20
