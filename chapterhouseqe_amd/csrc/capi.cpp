@@ -261,13 +261,17 @@ chq_status chq_filter_records_coalesced(chq_ctx* ctx, int n_records, const Arrow
     if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
       throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
     check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    PhaseTimer pt("chq_filter_records_coalesced");
     std::vector<Batch> in((size_t)n_records);
     for (int i = 0; i < n_records; ++i) require(recs[i], "record");
     for_each_parallel(n_records, [&](int i) { in[(size_t)i] = import_batch(recs[i], schema); });
+    pt.mark("import");
     std::vector<int64_t> rows;
     Batch res = filter_records_coalesced(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &rows);
+    pt.mark("filter");
     if (rows_per_record) for (int i = 0; i < n_records; ++i) rows_per_record[i] = rows[(size_t)i];
     export_batch(std::move(res), out_device, out, out_schema);
+    pt.mark("export");
   });
 }
 

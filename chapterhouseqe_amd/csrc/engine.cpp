@@ -3,6 +3,8 @@
 // RU/record_projection.rs:16-76, compute_value = RU/compute_value.rs:57-344 (RU = src/handlers/
 // operator_handler/operators/record_utils of the reference).
 #include "engine.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstdlib>
@@ -445,6 +447,22 @@ std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* al
     out.push_back(std::move(p));
   }
   return out;
+}
+
+PhaseTimer::PhaseTimer(const char* w) : what(w) {
+  static const bool enabled = [] { const char* e = getenv("CHQ_TIMING"); return e && *e == '1'; }();
+  on = enabled;
+  if (on) t0 = last = std::chrono::steady_clock::now();
+}
+void PhaseTimer::mark(const char* phase) {
+  if (!on) return;
+  const auto now = std::chrono::steady_clock::now();
+  line += std::string(" ") + phase + "=" + std::to_string(std::chrono::duration<double, std::micro>(now - last).count()).substr(0, 8) + "us";
+  last = now;
+}
+PhaseTimer::~PhaseTimer() {
+  if (!on) return;
+  fprintf(stderr, "[chq timing] %s total=%.1fus%s\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), line.c_str());
 }
 
 // =================================================================================================
@@ -1573,7 +1591,9 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     const size_t nc = recs[0].cols.size();
     std::vector<int> utf8_cols;
     for (size_t i = 0; i < nc; ++i) if (recs[0].cols[i].type == T_UTF8) utf8_cols.push_back((int)i);
+    PhaseTimer pt("device_concat_path");
     const std::vector<std::vector<int64_t>> ubytes = device_utf8_bytes(ctx, recs, utf8_cols);
+    pt.mark("utf8_sizes");
     std::vector<size_t> cuts{0};
     {
       std::vector<int64_t> bytes(utf8_cols.size(), 0);
@@ -1595,11 +1615,13 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
       const size_t b0 = cuts[k], b1 = cuts[k + 1];
       // (a chunk of one batch -- e.g. a 2 GB Utf8 column on its own -- is filtered in place: nothing to join)
       Batch cat = b1 - b0 == 1 ? to_device(ctx, recs[b0]) : concat_device_batches(ctx, recs, b0, b1, utf8_cols, ubytes);
+      pt.mark("join_launch");
       SplitRequest split;
       int64_t at = 0;
       for (size_t b = b0; b < b1; ++b) { split.starts.push_back(at); at += recs[b].nrows; }
       split.starts.push_back(at);
       Batch res = filter_record(ctx, cat, plan_columns(cat, aliases), expr, &split);
+      pt.mark("filter_record");
       add_stats(acc, ctx.stats);
       if (co) {
         for (size_t b = b0; b < b1; ++b) co->rows.push_back(split.bounds[b - b0 + 1] - split.bounds[b - b0]);

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -190,6 +191,15 @@ std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* al
 
 // Arrow C format string -> column kind and byte width (throws CHQ_ERR_NOT_SUPPORTED outside the build's scope)
 void parse_arrow_format(const char* format, DType* type, int* width);
+
+// Wall-clock phases of one call, printed to stderr when the environment has CHQ_TIMING=1 (development aid; off: one getenv
+// per process).
+struct PhaseTimer {
+  const char* what; bool on; std::chrono::steady_clock::time_point t0, last; std::string line;
+  explicit PhaseTimer(const char* w);
+  void mark(const char* phase);
+  ~PhaseTimer();
+};
 
 // ---- Arrow IPC stream with the body in HBM (ipc.cpp) ------------------------------------------------------------------
 struct IpcMessage {
