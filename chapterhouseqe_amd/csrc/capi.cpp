@@ -50,18 +50,8 @@ void require(const void* p, const char* what) { if (!p) throw ChqError{CHQ_ERR_I
 // the other (~0.3 + 0.4 us each) used to be 93 % of a group call (round 1).  The first error, if any, is rethrown.
 template <class F>
 void for_each_parallel(int n, F&& f) {
-  unsigned T = n < 4096 ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  if (T <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-  std::vector<std::thread> ts;
-  std::vector<std::exception_ptr> errs(T);
-  const int per = (n + (int)T - 1) / (int)T;
-  for (unsigned t = 0; t < T; ++t)
-    ts.emplace_back([&, t] {
-      try { for (int i = (int)t * per; i < std::min(n, (int)(t + 1) * per); ++i) f(i); }
-      catch (...) { errs[t] = std::current_exception(); }
-    });
-  for (auto& th : ts) th.join();
-  for (auto& e : errs) if (e) std::rethrow_exception(e);
+  if (n < 2048) { for (int i = 0; i < n; ++i) f(i); return; }
+  pool_ranges((size_t)n, 1024, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) f((int)i); });
 }
 
 }  // namespace

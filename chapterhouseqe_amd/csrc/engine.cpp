@@ -3,6 +3,9 @@
 // RU/record_projection.rs:16-76, compute_value = RU/compute_value.rs:57-344 (RU = src/handlers/
 // operator_handler/operators/record_utils of the reference).
 #include "engine.hpp"
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 
@@ -447,6 +450,77 @@ std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* al
     out.push_back(std::move(p));
   }
   return out;
+}
+
+namespace {
+class WorkPool {
+ public:
+  WorkPool() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n = std::min(16u, hw) - 1;   // + the calling thread
+    for (unsigned i = 0; i < n; ++i) threads_.emplace_back([this] { worker(); });
+  }
+  ~WorkPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  unsigned width() const { return (unsigned)threads_.size() + 1; }
+  void run(unsigned tasks, const std::function<void(unsigned)>& f) {
+    if (tasks == 0) return;
+    std::unique_lock<std::mutex> busy(run_m_, std::try_to_lock);
+    if (tasks == 1 || threads_.empty() || !busy.owns_lock()) { for (unsigned t = 0; t < tasks; ++t) f(t); return; }
+    std::unique_lock<std::mutex> l(m_);
+    job_ = &f; next_ = 0; total_ = tasks; finished_ = 0; error_ = nullptr; ++epoch_;
+    cv_.notify_all();
+    drain(l);
+    done_cv_.wait(l, [this] { return finished_ == total_; });
+    job_ = nullptr;
+    if (error_) { auto e = error_; error_ = nullptr; l.unlock(); std::rethrow_exception(e); }
+  }
+
+ private:
+  void drain(std::unique_lock<std::mutex>& l) {   // called with m_ held
+    while (job_ && next_ < total_) {
+      const unsigned t = next_++;
+      const auto* f = job_;
+      l.unlock();
+      std::exception_ptr err;
+      try { (*f)(t); } catch (...) { err = std::current_exception(); }
+      l.lock();
+      if (err && !error_) error_ = err;
+      if (++finished_ == total_) done_cv_.notify_all();
+    }
+  }
+  void worker() {
+    std::unique_lock<std::mutex> l(m_);
+    unsigned seen = 0;
+    while (true) {
+      cv_.wait(l, [&] { return stop_ || epoch_ != seen; });
+      if (stop_) return;
+      seen = epoch_;
+      drain(l);
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_, run_m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(unsigned)>* job_ = nullptr;
+  unsigned next_ = 0, total_ = 0, finished_ = 0, epoch_ = 0;
+  std::exception_ptr error_;
+  bool stop_ = false;
+};
+WorkPool& work_pool() { static WorkPool p; return p; }
+}  // namespace
+
+void pool_run(unsigned tasks, const std::function<void(unsigned)>& f) { work_pool().run(tasks, f); }
+unsigned pool_width() { return work_pool().width(); }
+void pool_ranges(size_t n, size_t grain, const std::function<void(size_t, size_t)>& f) {
+  if (n == 0) return;
+  const size_t want = grain ? (n + grain - 1) / grain : 1;
+  const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(want, pool_width()));
+  const size_t per = (n + T - 1) / T;
+  pool_run(T, [&](unsigned t) { const size_t i0 = std::min(n, (size_t)t * per), i1 = std::min(n, (size_t)(t + 1) * per); if (i0 < i1) f(i0, i1); });
 }
 
 PhaseTimer::PhaseTimer(const char* w) : what(w) {
@@ -1217,14 +1291,9 @@ void add_stats(chq_call_stats& acc, const chq_call_stats& s) {
 // link 55 GB/s: packing a group single-threaded would be the slowest step of a host-resident call)
 template <class F>
 void parallel_ranges(size_t n, size_t bytes, F&& f) {
-  unsigned T = bytes < ((size_t)8 << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-  if (T > n) T = (unsigned)n;
-  if (T <= 1) { f((size_t)0, n); return; }
-  const size_t per = (n + T - 1) / T;
-  std::vector<std::thread> ts;
-  for (unsigned t = 1; t < T; ++t) ts.emplace_back([&f, t, per, n] { f(std::min(n, t * per), std::min(n, (t + 1) * per)); });
-  f((size_t)0, std::min(n, per));
-  for (auto& th : ts) th.join();
+  if (bytes < ((size_t)8 << 20) || n < 2) { f((size_t)0, n); return; }
+  const size_t T = std::min<size_t>(std::min<size_t>(8, pool_width()), n);
+  pool_ranges(n, (n + T - 1) / T, [&](size_t i0, size_t i1) { f(i0, i1); });
 }
 
 // ---- host-side concatenation of a group (general column kinds) -----------------------------------------------
@@ -1358,6 +1427,21 @@ Batch concat_device_batches(Context& ctx, const std::vector<Batch>& recs, size_t
   // ---- tables: [row_at (nb+1)] then per column [src nb] [aux nb | -] [bitoff nb | -] [byte_at nb+1 | -] [vsrc nb, vbitoff nb | -]
   struct ColPlan { size_t src = 0, aux = 0, bitoff = 0, byte_at = 0, vsrc = 0, vbitoff = 0; bool validity = false; int utf8_k = -1; };
   std::vector<ColPlan> plan(nc);
+  // one pass over the batches on the pool's threads (every visit of a Batch is a cache miss at 10^4 batches): row counts
+  // into a dense array, "does any batch carry nulls" per column
+  std::vector<int64_t> batch_rows(nb, 0);
+  {
+    std::vector<std::atomic<int>> any_nulls(nc);
+    for (auto& a : any_nulls) a.store(0);
+    pool_ranges(nb, 2048, [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; ++k) {
+        const Batch& rb = recs[b0 + k];
+        batch_rows[k] = rb.nrows;
+        for (size_t c = 0; c < nc; ++c) if (rb.cols[c].validity && rb.cols[c].null_count != 0) any_nulls[c].store(1, std::memory_order_relaxed);
+      }
+    });
+    for (size_t c = 0; c < nc; ++c) plan[c].validity = any_nulls[c].load() != 0;
+  }
   size_t words = nb + 1;
   for (size_t c = 0; c < nc; ++c) {
     const Column& c0 = recs[b0].cols[c];
@@ -1368,38 +1452,48 @@ Batch concat_device_batches(Context& ctx, const std::vector<Batch>& recs, size_t
       plan[c].utf8_k = (int)(std::find(utf8_cols.begin(), utf8_cols.end(), (int)c) - utf8_cols.begin());
     }
     if (c0.type == T_BOOL) { plan[c].bitoff = words; words += nb; }
-    for (size_t b = b0; b < b1 && !plan[c].validity; ++b) plan[c].validity = recs[b].cols[c].validity && recs[b].cols[c].null_count != 0;
     if (plan[c].validity) { plan[c].vsrc = words; words += nb; plan[c].vbitoff = words; words += nb; }
   }
   ensure_pinned_table(ctx, words * 8);
   u64* h = (u64*)ctx.pinned_tbl;
   int64_t total = 0;
-  for (size_t k = 0; k < nb; ++k) { h[k] = (u64)total; total += recs[b0 + k].nrows; }
+  for (size_t k = 0; k < nb; ++k) { h[k] = (u64)total; total += batch_rows[k]; }
   h[nb] = (u64)total;
   cat.nrows = total;
   std::vector<int64_t> total_bytes(nc, 0);
   std::vector<int64_t> known_nulls(nc, 0);
-  for (size_t c = 0; c < nc; ++c) {
+  for (size_t c = 0; c < nc; ++c) {   // running byte positions first (serial, over a dense array)
     const ColPlan& pl = plan[c];
+    if (recs[b0].cols[c].type != T_UTF8) continue;
     int64_t bytes = 0;
-    for (size_t k = 0; k < nb; ++k) {
-      const Column& col = recs[b0 + k].cols[c];
-      h[pl.src + k] = (u64)(uintptr_t)(col.type == T_BOOL ? (const void*)col.values : col.values0());
-      if (col.type == T_UTF8) {
-        h[pl.aux + k] = (u64)(uintptr_t)col.data;
-        h[pl.byte_at + k] = (u64)bytes;
-        bytes += utf8_bytes[(size_t)pl.utf8_k][b0 + k];
-      }
-      if (col.type == T_BOOL) h[pl.bitoff + k] = (u64)col.offset;
-      if (pl.validity) {
-        const bool has = col.validity && col.null_count != 0;
-        h[pl.vsrc + k] = has ? (u64)(uintptr_t)col.validity : 0;
-        h[pl.vbitoff + k] = (u64)col.offset;
-        if (has && col.null_count > 0) known_nulls[c] += col.null_count;
+    const std::vector<int64_t>& ub = utf8_bytes[(size_t)pl.utf8_k];
+    for (size_t k = 0; k < nb; ++k) { h[pl.byte_at + k] = (u64)bytes; bytes += ub[b0 + k]; }
+    h[pl.byte_at + nb] = (u64)bytes; total_bytes[c] = bytes;
+  }
+  // the pointers: one pass over the batches (each batch's columns lie together in memory), on the pool's threads --
+  // at 10^4 batches this is pointer chasing through ~10 MB of Batch / Column objects
+  std::mutex nulls_m;
+  pool_ranges(nb, 2048, [&](size_t k0, size_t k1) {
+    std::vector<int64_t> nulls(nc, 0);
+    for (size_t k = k0; k < k1; ++k) {
+      const Batch& rb = recs[b0 + k];
+      for (size_t c = 0; c < nc; ++c) {
+        const ColPlan& pl = plan[c];
+        const Column& col = rb.cols[c];
+        h[pl.src + k] = (u64)(uintptr_t)(col.type == T_BOOL ? (const void*)col.values : col.values0());
+        if (col.type == T_UTF8) h[pl.aux + k] = (u64)(uintptr_t)col.data;
+        if (col.type == T_BOOL) h[pl.bitoff + k] = (u64)col.offset;
+        if (pl.validity) {
+          const bool has = col.validity && col.null_count != 0;
+          h[pl.vsrc + k] = has ? (u64)(uintptr_t)col.validity : 0;
+          h[pl.vbitoff + k] = (u64)col.offset;
+          if (has && col.null_count > 0) nulls[c] += col.null_count;
+        }
       }
     }
-    if (recs[b0].cols[c].type == T_UTF8) { h[pl.byte_at + nb] = (u64)bytes; total_bytes[c] = bytes; }
-  }
+    std::lock_guard<std::mutex> l(nulls_m);
+    for (size_t c = 0; c < nc; ++c) known_nulls[c] += nulls[c];
+  });
   auto d_tbl = make_device_buffer(words * 8 + 16, ctx.device);
   check_hip(hipMemcpyAsync(d_tbl->ptr, h, words * 8, hipMemcpyHostToDevice, ctx.stream), "upload concat tables");
   const u64* d = (const u64*)d_tbl->ptr;
@@ -1464,7 +1558,8 @@ std::vector<std::vector<int64_t>> device_utf8_bytes(Context& ctx, const std::vec
   int32_t* d_ends = (int32_t*)((u64*)d_tbl->ptr + words);
   int32_t* h_ends = (int32_t*)(h + words);
   for (size_t k = 0; k < utf8_cols.size(); ++k) {
-    for (size_t b = 0; b < nb; ++b) h[nb + 1 + b] = (u64)(uintptr_t)recs[b].cols[utf8_cols[k]].values0();
+    const int uc = utf8_cols[k];
+    pool_ranges(nb, 2048, [&](size_t i0, size_t i1) { for (size_t b = i0; b < i1; ++b) h[nb + 1 + b] = (u64)(uintptr_t)recs[b].cols[(size_t)uc].values0(); });
     check_hip(hipMemcpyAsync(d_tbl->ptr, h, words * 8, hipMemcpyHostToDevice, ctx.stream), "upload offsets table");
     ConcatParams cp{};
     cp.nb = (int64_t)nb; cp.row_at = (const int64_t*)d_tbl->ptr; cp.src = (const u64*)d_tbl->ptr + nb + 1; cp.ends = d_ends;

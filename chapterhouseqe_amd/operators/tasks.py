@@ -240,7 +240,7 @@ class MaterializeFilesTask:
     def _write_parquet(self, proj_rec, path: str) -> None:
         """materialize_files_task.rs:128-141 (AsyncArrowWriter ... write ... close).  A device-resident result is encoded on
         the GPU (`chq_record_to_parquet`) and only the finished file image reaches the host; column types that encoder does
-        not write (and the oracle-driven CPU tests, whose batches never were on a device) go through pyarrow's writer."""
+        not write (and host-resident results, e.g. from an injected `project_fn`) go through pyarrow's writer."""
         import pyarrow as pa
         import pyarrow.parquet as pq
         if isinstance(proj_rec, record_utils.DeviceRecordBatch):
