@@ -122,6 +122,9 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "enable_minus") ctx->c.opt_enable_minus = value != 0;
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
     else if (k == "fold_utf8") ctx->c.opt_fold_utf8 = value != 0;
+    else if (k == "large_host") ctx->c.opt_large_host = value != 0;
+    else if (k == "large_host_chunk") { if (value < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "large_host_chunk must not be negative"}; ctx->c.opt_large_host_chunk = value; }
+    else if (k == "large_host_rows") { if (value < 1) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "large_host_rows must be positive"}; ctx->c.opt_large_host_rows = value; }
     else if (k == "stash") { if (value < -1 || value > MAX_STASH) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "stash must be -1..2"}; ctx->c.opt_stash = value; }
     else if (k == "small_host") ctx->c.opt_small_host = value != 0;
     else if (k == "fuse") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "fuse must be 0..2"}; ctx->c.opt_fuse = value; }
@@ -182,7 +185,8 @@ chq_status chq_filter_record(chq_ctx* ctx, const ArrowDeviceArray* rec, const Ar
     Batch in = import_batch(rec, schema);
     if (out_device == ARROW_DEVICE_CPU && !in.on_device) {   // the reference's calling pattern: small host batch in, host batch out
       Batch small;
-      if (filter_record_small_host(ctx->c, in, table_aliases, expr->e, &small)) {
+      if (filter_record_small_host(ctx->c, in, table_aliases, expr->e, &small) ||
+          filter_record_large_host(ctx->c, in, table_aliases, expr->e, &small)) {
         export_batch(std::move(small), ARROW_DEVICE_CPU, out, out_schema);
         return;
       }

@@ -120,6 +120,9 @@ struct Context {
   int64_t opt_tile_kind = -1;       // -1 auto
   bool opt_enable_minus = false;
   bool opt_time_kernels = false;
+  int64_t opt_large_host = 1;       // host batches of opt_large_host_rows rows or more: chunked, uploads and downloads overlapped
+  int64_t opt_large_host_rows = 8 << 20;
+  int64_t opt_large_host_chunk = 0;  // rows per chunk (0: about 64 MB of input)
   int64_t opt_fold_utf8 = 1;        // short-string Utf8 columns are filtered inside filter_fused_kernel (0: always the separate Utf8 pass)
   int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots
   int64_t opt_fuse = 1;             // chq_filter_project_record's single-pass kernel: 0 never, 1 when it moves clearly fewer bytes, 2 whenever possible
@@ -171,6 +174,7 @@ Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanCo
 // A small host batch, host result: columns staged through one pinned block each way (one H2D, one D2H, one stream
 // synchronisation).  False = outside its scope or an error was flagged: take the general path.
 bool filter_record_small_host(Context& ctx, const Batch& rec_host, const chq_table_aliases* aliases, const Expr& expr, Batch* result);
+bool filter_record_large_host(Context& ctx, const Batch& rec_host, const chq_table_aliases* aliases, const Expr& expr, Batch* result);
 // one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
                                   const Expr& expr, bool out_on_device);
