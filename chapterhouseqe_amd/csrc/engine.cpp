@@ -1877,18 +1877,42 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   const size_t ncols = recs[0].cols.size();
   if (ncols == 0) return per_batch_loop();
   bool plain = (int)ncols <= MAX_OUT, same_schema = true, all_host = !recs[0].on_device;
+  // `foldable`: device-resident, non-null, fixed-width or Utf8 columns -- short-string Utf8 columns can then be filtered
+  // straight out of the batches by the one-launch path (their offsets and bytes per batch ride in the group table)
+  bool foldable = (int)ncols <= MAX_OUT && ctx.opt_fold_utf8 && ctx.opt_group_fold;
   for (const Batch& r : recs) {
     if (r.cols.size() != ncols || r.nrows < 2) return per_batch_loop();
     all_host &= !r.on_device;
+    foldable &= r.on_device && r.device_id == ctx.device;
     for (size_t i = 0; i < ncols; ++i) {
       const Column& c = r.cols[i];
       same_schema &= c.type == recs[0].cols[i].type && c.width == recs[0].cols[i].width && c.format == recs[0].cols[i].format;
       plain &= c.type != T_BOOL && c.type != T_UTF8 && !(c.validity && c.null_count != 0 && (r.on_device || c.null_count > 0 ||
                count_nulls_host(c.validity, c.offset, c.length) != 0));
+      foldable &= c.type != T_BOOL && !(c.validity && c.null_count != 0) && (c.type != T_UTF8 || c.data != nullptr);
     }
   }
   if (!same_schema) return per_batch_loop();
-  if (!plain) {
+  std::vector<int> fold_utf8;                          // the Utf8 columns of a foldable group
+  std::vector<std::vector<int64_t>> fold_bytes;        // their data bytes per batch
+  std::vector<int64_t> fold_cap;
+  if (!plain && foldable) {
+    for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type == T_UTF8) fold_utf8.push_back((int)i);
+    int64_t rows_all = 0;
+    for (const Batch& r : recs) rows_all += r.nrows;
+    foldable = !fold_utf8.empty() && (int)fold_utf8.size() <= MAX_FOLD_UTF8 && rows_all < (1ll << 31) - 64;
+    if (foldable) {
+      fold_bytes = device_utf8_bytes(ctx, recs, fold_utf8);
+      for (const auto& per_batch : fold_bytes) {
+        int64_t cap = 0;
+        for (int64_t v : per_batch) cap += v;
+        fold_cap.push_back(cap);
+        foldable &= cap <= rows_all * 24 && cap < (1ll << 31) - 64;   // short strings that fit ONE output column
+      }
+    }
+  }
+  const bool fold = !plain && foldable;
+  if (!plain && !fold) {
     bool all_device = true;
     for (const Batch& r : recs) all_device &= r.on_device && r.device_id == ctx.device;
     const bool host_case = all_host && !out_on_device;
@@ -1906,13 +1930,23 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
       return per_batch_loop();   // a data-dependent error: the loop reports the earliest failing batch's
     }
   }
+  // a foldable group that turns out not to fit the one-launch path is joined on the device instead
+  auto other_path = [&]() -> std::vector<Batch> {
+    if (!fold) return per_batch_loop();
+    try {
+      return device_concat_path();
+    } catch (const ChqError& e) {
+      if (e.code == CHQ_ERR_OUT_OF_MEMORY || e.code == CHQ_ERR_DEVICE) throw;
+      return per_batch_loop();
+    }
+  };
   int64_t total_rows = 0, max_rows = 0;
   const bool host_in = !recs[0].on_device;
   for (const Batch& r : recs) {
     if (r.cols.size() != ncols || r.nrows < 2 || r.on_device == host_in) return per_batch_loop();
     for (size_t i = 0; i < ncols; ++i) {
       const Column& c = r.cols[i];
-      if (c.type == T_BOOL || c.type == T_UTF8 || c.type != recs[0].cols[i].type || c.width != recs[0].cols[i].width) return per_batch_loop();
+      if (c.type == T_BOOL || (c.type == T_UTF8 && !fold) || c.type != recs[0].cols[i].type || c.width != recs[0].cols[i].width) return per_batch_loop();
       if (c.validity && c.null_count != 0) {
         if (r.on_device || c.null_count > 0) return per_batch_loop();
         if (count_nulls_host(c.validity, c.offset, c.length) != 0) return per_batch_loop();
@@ -1932,7 +1966,11 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     if (e.code != CHQ_INTERNAL_PROGRAM_LIMIT) throw;
     return per_batch_loop();   // oversized predicate: every batch materialises its own temporaries
   }
-  if (!lw.strs.empty()) return per_batch_loop();
+  if (!lw.strs.empty()) return other_path();
+  if (fold) {   // the predicate itself must not read a string column, and the wide / temporaries instantiation has no Utf8 form
+    for (int r : lw.refs) if (recs[0].cols[(size_t)r].type == T_UTF8) return other_path();
+    if (lw.wide || lw.num_temps > 0) return other_path();
+  }
 
   ctx.stats = chq_call_stats{};
   ctx.stats.rows_in = total_rows;
@@ -1996,11 +2034,12 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
 
   // column order of the launch: the stashed predicate column goes last (see filter_record)
   std::vector<int> launch_cols;
-  for (size_t i = 0; i < ncols; ++i) launch_cols.push_back((int)i);
+  for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type != T_UTF8) launch_cols.push_back((int)i);
   FilterParams p{};
   pick_stash(p, ctx, lw, recs[0].cols, launch_cols, tile_kind);
-  const size_t nrefs = lw.refs.size(), nout = launch_cols.size();
-  const size_t stride = (wpb > 0 ? 1 : 2) + nrefs + nout;
+  const size_t nrefs = lw.refs.size(), nout = launch_cols.size(), nu = fold ? fold_utf8.size() : 0;
+  const size_t stride = (wpb > 0 ? 1 : 2) + nrefs + nout + 2 * nu;   // per Utf8 column: the batch's offsets and bytes
+  if (fold && tile_kind == 2) return other_path();
 
   // ---- table (+ index of every batch's last tile in tile mode): built in pinned memory, one upload ---------------
   const size_t tbl_words = (wpb > 0 ? nb : (size_t)ntiles) * stride;
@@ -2018,12 +2057,14 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
         *w++ = (u64)rows;
         for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
         for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
+        for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = (u64)(uintptr_t)recs[b].cols[(size_t)fold_utf8[k]].data; }
         continue;
       }
       for (int64_t r0 = 0; r0 < rows; r0 += tile_rows, ++tile) {
         *w++ = (u64)r0; *w++ = (u64)rows;
         for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
         for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
+        for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = (u64)(uintptr_t)recs[b].cols[(size_t)fold_utf8[k]].data; }
       }
       h_idx[b] = tile - 1;   // rows >= 2: every batch owns at least one tile
     }
@@ -2033,11 +2074,26 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   u64* d_cnt = (u64*)((uint8_t*)d_tbl->ptr + bytes_tbl + bytes_idx);
 
   // ---- dense outputs ---------------------------------------------------------------------------------------
-  std::vector<BufferPtr> dense(ncols);
+  std::vector<BufferPtr> dense(ncols), dense_data(ncols), fold_status;
   for (size_t i = 0; i < ncols; ++i) {
+    if (recs[0].cols[i].type == T_UTF8) continue;
     dense[i] = make_device_buffer((size_t)(total_rows * recs[0].cols[i].width) + 16, ctx.device);
     ctx.stats.bytes_read_alg += total_rows * recs[0].cols[i].width;
   }
+  for (size_t k = 0; k < nu; ++k) {   // Utf8 columns: joined offsets (from 0) and bytes, capacity = the input bytes
+    const size_t i = (size_t)fold_utf8[k];
+    dense[i] = make_device_buffer((size_t)(total_rows + 2) * 4, ctx.device);
+    dense_data[i] = make_device_buffer((size_t)fold_cap[k] + 64, ctx.device);
+    auto st = make_device_buffer((size_t)(ntiles + 1) * 8, ctx.device);
+    check_hip(hipMemsetAsync(st->ptr, 0, (size_t)(ntiles + 1) * 8, ctx.stream), "memset byte-scan status");
+    fold_status.push_back(st);
+    Utf8Fold& f = p.utf8[k];
+    f.in_offsets = nullptr; f.in_data = nullptr;   // per batch, from the table
+    f.out_offsets = (int32_t*)dense[i]->ptr; f.out_data = (uint8_t*)dense_data[i]->ptr;
+    f.status = (u64*)st->ptr; f.total_bytes = &ds->fold_bytes[k];
+    ctx.stats.bytes_read_alg += total_rows * 8;
+  }
+  p.n_utf8 = (int32_t)nu;
   p.nrows = ntiles * tile_rows;   // only locates the last tile; per-tile row ranges come from the table
   p.status = dev_status(ctx);
   p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
@@ -2069,18 +2125,29 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
   if (hs->err != ERR_NONE) return per_batch_loop();   // reports the earliest failing batch, as the reference's loop would
+  (void)fold_status;
   const int64_t total = (int64_t)hs->total;
   ctx.stats.rows_out = total;
-  for (size_t i = 0; i < ncols; ++i) ctx.stats.bytes_written_alg += total * recs[0].cols[i].width;
+  std::vector<int64_t> out_bytes(ncols, 0);   // Utf8 columns: bytes of the joined output
+  for (size_t k = 0; k < nu; ++k) {
+    out_bytes[(size_t)fold_utf8[k]] = (int64_t)hs->fold_bytes[k];
+    ctx.stats.bytes_read_alg += (int64_t)hs->fold_bytes[k]; ctx.stats.bytes_written_alg += (total + 1) * 4 + (int64_t)hs->fold_bytes[k];
+  }
+  for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type != T_UTF8) ctx.stats.bytes_written_alg += total * recs[0].cols[i].width;
 
   // ---- slice the dense outputs ---------------------------------------------------------------------------------
-  std::vector<BufferPtr> host_dense;
+  std::vector<BufferPtr> host_dense, host_data(ncols);
   if (!out_on_device) {
     for (size_t i = 0; i < ncols; ++i) {
-      const size_t bytes = (size_t)(total * recs[0].cols[i].width);
+      const bool u8 = recs[0].cols[i].type == T_UTF8;
+      const size_t bytes = u8 ? (size_t)(total + 1) * 4 : (size_t)(total * recs[0].cols[i].width);
       auto hb = make_host_buffer(bytes + 16);
       if (bytes) check_hip(hipMemcpyAsync(hb->ptr, dense[i]->ptr, bytes, hipMemcpyDeviceToHost, ctx.stream), "download dense column");
       host_dense.push_back(hb);
+      if (u8) {
+        host_data[i] = make_host_buffer((size_t)out_bytes[i] + 16);
+        if (out_bytes[i]) check_hip(hipMemcpyAsync(host_data[i]->ptr, dense_data[i]->ptr, (size_t)out_bytes[i], hipMemcpyDeviceToHost, ctx.stream), "download string bytes");
+      }
     }
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   }
@@ -2091,6 +2158,10 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
       Column c = empty_like(recs[0].cols[i]);
       const BufferPtr& buf = out_on_device ? dense[i] : host_dense[i];
       c.values = (const uint8_t*)buf->ptr; c.length = total; c.owned.push_back(buf);
+      if (c.type == T_UTF8) {
+        const BufferPtr& db = out_on_device ? dense_data[i] : host_data[i];
+        c.data = (const uint8_t*)db->ptr; c.data_bytes = out_bytes[i]; c.owned.push_back(db);
+      }
       co->out.cols.push_back(std::move(c));
     }
     int64_t prev = 0;
@@ -2108,9 +2179,13 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     for (size_t i = 0; i < ncols; ++i) {
       Column c = empty_like(recs[b].cols[i]);
       const BufferPtr& buf = out_on_device ? dense[i] : host_dense[i];
-      c.values = (const uint8_t*)buf->ptr + begin * c.width;
       c.length = o.nrows;
       c.owned.push_back(buf);
+      if (c.type == T_UTF8) {   // a slice of the joined column: shared offsets and bytes, Arrow offset = first row
+        const BufferPtr& db = out_on_device ? dense_data[i] : host_data[i];
+        c.values = (const uint8_t*)buf->ptr; c.offset = begin;
+        c.data = (const uint8_t*)db->ptr; c.owned.push_back(db);
+      } else c.values = (const uint8_t*)buf->ptr + begin * c.width;
       o.cols.push_back(std::move(c));
     }
     begin = end;

@@ -1077,15 +1077,18 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
       for (int u = 0; u < NU; ++u) {
         if (u >= p.n_utf8) break;
         uint32_t bytes = 0;   // of this lane's selected rows; a wave's total stays below 2^31 (int32 offsets)
+        // (batch-group launch: the wave's batch has its own offsets, behind the program's and the copied columns' pointers)
+        const int32_t* uoffs = p.utf8[u].in_offsets;
+        if constexpr (PARTIAL) { if (it.ptr_row) uoffs = (const int32_t*)it.ptr_row[p.pb.n_refs + p.n_out + 2 * u]; }
         if (it.nact == 64 * R) {
-          const int32_t* offs = p.utf8[u].in_offsets + it.w0;
+          const int32_t* offs = uoffs + it.w0;
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             const int32_t o = offs[j * 64 + lane], n = offs[j * 64 + lane + 1];
             bytes += ((selv >> j) & 1) ? (uint32_t)(n - o) : 0u;
           }
         } else if (it.nact > 0) {   // rows [w0, w0 + nact): offsets w0 .. w0 + nact exist, anything past them reads 0
-          const auto rs = wave_rows_rsrc(p.utf8[u].in_offsets, it.w0, 4, it.nact + 1);
+          const auto rs = wave_rows_rsrc(uoffs, it.w0, 4, it.nact + 1);
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             const uint32_t o = buf_load<uint32_t>(rs, j * 64 + lane), n = buf_load<uint32_t>(rs, j * 64 + lane + 1);
@@ -1190,9 +1193,14 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     // Utf8 columns: the offsets of the first step are requested before the fixed-width copies, whose loads they join
     constexpr int CH = 4;                                   // 64-row groups per step (8 spill at the 128-VGPR budget of the 1024-thread tile: 3.0 ms vs 2.2 ms)
     uint32_t on[CH], nn[CH];
+    auto utf8_ptr = [&](int u, int which) -> const void* {   // which: 0 offsets, 1 data; per batch in a group launch
+      if constexpr (PARTIAL) { if (in_row) return (const void*)in_row[p.n_out + 2 * u + which]; }
+      return which ? (const void*)p.utf8[u].in_data : (const void*)p.utf8[u].in_offsets;
+    };
     auto load_offsets = [&](int u, int j0) __attribute__((always_inline)) {
-      const int32_t* offs = p.utf8[u].in_offsets + w0;
-      const auto rs = wave_rows_rsrc(p.utf8[u].in_offsets, w0, 4, nact + 1);
+      const int32_t* base = (const int32_t*)utf8_ptr(u, 0);
+      const int32_t* offs = base + w0;
+      const auto rs = wave_rows_rsrc(base, w0, 4, nact + 1);
 #pragma unroll
       for (int jj = 0; jj < CH; ++jj) {
         const uint32_t e = (uint32_t)((j0 + jj) * 64 + lane);
@@ -1300,7 +1308,8 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         if (u >= p.n_utf8) break;
-        const Utf8Fold uf = p.utf8[u];
+        Utf8Fold uf = p.utf8[u];
+        uf.in_data = (const uint8_t*)utf8_ptr(u, 1);
         uint32_t boff = s_ubase[u];                         // first output byte of this wave's rows
         for (int w = 0; w < wv; ++w) boff += s_wave_bytes[buf][u][w];
         boff = __builtin_amdgcn_readfirstlane(boff);
@@ -1986,7 +1995,7 @@ hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int
 #define LFU(B, RR, S, F) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, false, 0, true, S, F, MAX_FOLD_UTF8>), dim3(grid), dim3(B), 0, stream, p); \
                               else hipLaunchKernelGGL((filter_fused_kernel<B, RR, false, 0, false, S, F, MAX_FOLD_UTF8>), dim3(grid), dim3(B), 0, stream, p); } while (0)
   if (p.n_utf8 > 0) {   // single-batch launches with Utf8 columns filtered in the same pass (tile kinds 0 and 1 only)
-    if (tile_kind == 2 || p.group || p.n_utf8 > MAX_FOLD_UTF8) return hipErrorInvalidValue;
+    if (tile_kind == 2 || p.n_utf8 > MAX_FOLD_UTF8 || (p.group && !partial)) return hipErrorInvalidValue;
     if (tile_kind == 0) { if (fast) LFU(1024, 16, STASH_SLOTS_K0, true); else LFU(1024, 16, STASH_SLOTS_K0, false); }
     else { if (fast) LFU(256, 8, STASH_SLOTS_K1, true); else LFU(256, 8, STASH_SLOTS_K1, false); }
     return hipGetLastError();
