@@ -349,3 +349,52 @@ def test_coalesced_output_is_the_concatenation_of_the_per_batch_results(ctx, dev
         assert batches_identical(got, exp), f"{sql}:\n{explain_diff(got, exp)}"
     with pytest.raises(chq.ChqError):
         chq.filter_records_coalesced([fixed_batch(10, 1), fixed_batch(10, 2)], empty_aliases(fixed_batch(10, 1)), parse_expr("nope > 1"), ctx=ctx)
+
+
+def test_device_groups_with_short_strings_are_filtered_straight_out_of_the_batches(ctx):
+    """device-resident, non-null groups with one or two short-string Utf8 columns take the one-launch path (their offsets and
+    bytes per batch ride in the group table, no join): uniform batches (wave-packed layout) and ragged ones (per-tile table),
+    small and large tiles, every batch against the oracle, the joined form against the per-batch form, and the joined-first
+    path (`group_fold` = 0) for the same answer"""
+    rng = np.random.default_rng(2024)
+
+    def batch(n, seed, two):
+        r = np.random.default_rng(seed)
+        cols = {"id": pa.array(r.integers(0, 1000, n).astype(np.int32)),
+                "s": pa.array(["w" * int(l) + str(i % 7) for i, l in enumerate(r.integers(0, 20, n))]),
+                "v": pa.array((r.random(n) * 100).astype(np.float32))}
+        if two:
+            cols["t"] = pa.array(["%x" % v for v in r.integers(0, 2**31, n)])
+            cols["k"] = pa.array(r.integers(-9, 9, n).astype(np.int64))
+        return pa.record_batch(cols)
+
+    for sizes, two in [([10_000] * 40, False), ([10_000] * 40, True), ([int(x) for x in rng.integers(2, 30_000, 25)], True),
+                       ([70_000, 3, 16_384, 16_385, 2, 50_000], False)]:
+        recs = [batch(n, 500 + i, two) for i, n in enumerate(sizes)]
+        al = empty_aliases(recs[0])
+        devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]
+        for sql in ["id % 2 = 0", "v > 10.0", "v > 99.0 and id > 5", "id < 0"]:
+            e = parse_expr(sql)
+            for tile_kind in (-1, 0, 1):
+                ctx.set_option("tile_kind", tile_kind)
+                try:
+                    got = chq.filter_records(devs, al, e, ctx=ctx)
+                    assert ctx.last_stats()["launches"] <= 2, (sql, tile_kind)      # ONE kernel (+ the batch-end gather in tile mode)
+                    for i, g in enumerate(got):
+                        assert batches_identical(g.to_host(), O.filter_record(recs[i], al, e)), (sql, tile_kind, i)
+                    big, per = chq.filter_records_coalesced(devs, al, e, ctx=ctx)
+                    assert per == [g.num_rows for g in got]
+                    joined = pa.Table.from_batches([g.to_host() for g in got]).combine_chunks().to_batches()
+                    if big.num_rows:
+                        assert batches_identical(big.to_host(), joined[0], check_nullable=False), (sql, tile_kind)
+                    ctx.set_option("group_fold", 0)
+                    ref = chq.filter_records(devs, al, e, ctx=ctx)
+                    ctx.set_option("group_fold", 1)
+                    for g, r in zip(got, ref):
+                        assert batches_identical(g.to_host(), r.to_host())
+                    host = chq.filter_records(devs, al, e, ctx=ctx, device_result=False)
+                    for g, h in zip(got, host):
+                        assert batches_identical(g.to_host(), h)
+                finally:
+                    ctx.set_option("tile_kind", -1)
+                    ctx.set_option("group_fold", 1)
