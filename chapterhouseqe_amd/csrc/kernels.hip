@@ -1988,27 +1988,46 @@ __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
 // partial: the launch may contain a tile that is not completely inside the batch
 // The FASTK instantiations serve the pre-decoded programs (32-bit types only: tile kinds 0 and 1), the others the generic
 // interpreter.
+// The file is compiled as four translation units (Makefile: -DCHQ_TU=1..4, in parallel), each instantiating its share of the
+// kernel templates above -- one unit took 3.5 minutes; without CHQ_TU everything is compiled in one.
+//   1: filter_fused_kernel without Utf8 columns   2: filter_fused_kernel with Utf8 columns
+//   3: filter_project_kernel, project_kernel       4: bit / Utf8 follow-up kernels, joins, IPC helpers
+#ifndef CHQ_TU
+#define CHQ_TU 0
+#endif
+hipError_t launch_filter_utf8(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
+
+#if CHQ_TU == 0 || CHQ_TU == 1
 hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
+  if (p.n_utf8 > 0) return launch_filter_utf8(p, tile_kind, partial, grid, stream);
   const bool fast = p.pb.fast_kind != FAST_NONE && tile_kind != 2;
 #define LF(B, RR, W, T, S, F) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, true, S, F>), dim3(grid), dim3(B), 0, stream, p); \
                                    else hipLaunchKernelGGL((filter_fused_kernel<B, RR, W, T, false, S, F>), dim3(grid), dim3(B), 0, stream, p); } while (0)
-#define LFU(B, RR, S, F) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, false, 0, true, S, F, MAX_FOLD_UTF8>), dim3(grid), dim3(B), 0, stream, p); \
-                              else hipLaunchKernelGGL((filter_fused_kernel<B, RR, false, 0, false, S, F, MAX_FOLD_UTF8>), dim3(grid), dim3(B), 0, stream, p); } while (0)
-  if (p.n_utf8 > 0) {   // single-batch launches with Utf8 columns filtered in the same pass (tile kinds 0 and 1 only)
-    if (tile_kind == 2 || p.n_utf8 > MAX_FOLD_UTF8 || (p.group && !partial)) return hipErrorInvalidValue;
-    if (tile_kind == 0) { if (fast) LFU(1024, 16, STASH_SLOTS_K0, true); else LFU(1024, 16, STASH_SLOTS_K0, false); }
-    else { if (fast) LFU(256, 8, STASH_SLOTS_K1, true); else LFU(256, 8, STASH_SLOTS_K1, false); }
-    return hipGetLastError();
-  }
   switch (tile_kind) {
     case 0: if (fast) LF(1024, 16, false, 0, STASH_SLOTS_K0, true); else LF(1024, 16, false, 0, STASH_SLOTS_K0, false); break;
     case 1: if (fast) LF(256, 8, false, 0, STASH_SLOTS_K1, true); else LF(256, 8, false, 0, STASH_SLOTS_K1, false); break;
     default: LF(256, 8, true, MAX_NUM_TEMPS, STASH_SLOTS_K2, false); break;
   }
-#undef LFU
 #undef LF
   return hipGetLastError();
 }
+#endif
+
+#if CHQ_TU == 0 || CHQ_TU == 2
+// launches with Utf8 columns filtered in the same pass (tile kinds 0 and 1; batch groups only in the PARTIAL instantiation)
+hipError_t launch_filter_utf8(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
+  const bool fast = p.pb.fast_kind != FAST_NONE && tile_kind != 2;
+#define LFU(B, RR, S, F) do { if (partial) hipLaunchKernelGGL((filter_fused_kernel<B, RR, false, 0, true, S, F, MAX_FOLD_UTF8>), dim3(grid), dim3(B), 0, stream, p); \
+                              else hipLaunchKernelGGL((filter_fused_kernel<B, RR, false, 0, false, S, F, MAX_FOLD_UTF8>), dim3(grid), dim3(B), 0, stream, p); } while (0)
+  if (tile_kind == 2 || p.n_utf8 > MAX_FOLD_UTF8 || (p.group && !partial)) return hipErrorInvalidValue;
+  if (tile_kind == 0) { if (fast) LFU(1024, 16, STASH_SLOTS_K0, true); else LFU(1024, 16, STASH_SLOTS_K0, false); }
+  else { if (fast) LFU(256, 8, STASH_SLOTS_K1, true); else LFU(256, 8, STASH_SLOTS_K1, false); }
+#undef LFU
+  return hipGetLastError();
+}
+#endif
+
+#if CHQ_TU == 0 || CHQ_TU == 3
 hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, hipStream_t stream) {
   const bool fast = tile_kind != 2 && p.pred.fast_kind != FAST_NONE && (p.n_proj == 0 || p.proj.fast_kind == FAST_UOPS);
   switch (tile_kind) {
@@ -2036,6 +2055,9 @@ hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, i
 #undef LP
   return hipGetLastError();
 }
+#endif
+
+#if CHQ_TU == 0 || CHQ_TU == 4
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL((bit_compact_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
   return hipGetLastError();
@@ -2227,5 +2249,7 @@ hipError_t launch_utf8_copy(const Utf8Params& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL((utf8_copy_kernel<256>), dim3(grid), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
+
+#endif
 
 }  // namespace chq
