@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
     "chq_record_copy_to_peer", "chq_record_to_ipc", "chq_record_from_ipc", "chq_ipc_describe",
     "chq_parquet_open", "chq_parquet_close", "chq_parquet_num_row_groups", "chq_parquet_row_group_num_rows",
-    "chq_parquet_describe", "chq_parquet_read_row_group", "chq_record_to_parquet",
+    "chq_parquet_describe", "chq_parquet_read_row_group", "chq_parquet_read_row_groups", "chq_record_to_parquet",
 ]
 
 
@@ -166,6 +166,7 @@ def lib():
         "chq_parquet_row_group_num_rows": (i64, [vp, C.c_int32]),
         "chq_parquet_describe": (ci, [vp, C.c_char_p, C.c_size_t]),
         "chq_parquet_read_row_group": (ci, [vp, vp, C.c_int32, ci, PDA, PS]),
+        "chq_parquet_read_row_groups": (ci, [vp, vp, C.c_int32, C.c_int32, ci, vp, vp]),
         "chq_record_to_parquet": (ci, [vp, PDA, PS, C.POINTER(ParquetImage)]),
     }
     for name, (res, args) in sig.items():

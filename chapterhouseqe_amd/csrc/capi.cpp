@@ -487,6 +487,31 @@ chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32
   });
 }
 
+chq_status chq_parquet_read_row_groups(chq_ctx* ctx, const chq_parquet* pq, int32_t first, int32_t count, int out_device,
+                                       ArrowDeviceArray* outs, ArrowSchema* out_schemas) {
+  if (!ctx || !pq) return CHQ_ERR_INVALID_HANDLE;
+  if (outs && out_schemas) for (int32_t i = 0; i < count; ++i) mark_released(&outs[i], &out_schemas[i]);
+  return guarded(ctx, [&] {
+    if (count > 0) { require(outs, "output arrays"); require(out_schemas, "output schemas"); }
+    if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
+      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    std::vector<Batch> res = parquet_read_row_groups(ctx->c, pq->file, first, count);
+    try {
+      for (size_t i = 0; i < res.size(); ++i) {
+        if (out_device == ARROW_DEVICE_CPU) res[i] = to_host(ctx->c, res[i]);
+        export_batch(std::move(res[i]), out_device, &outs[i], &out_schemas[i]);
+      }
+    } catch (...) {   // no partial output
+      for (int32_t i = 0; i < count; ++i) {
+        if (outs[i].array.release) outs[i].array.release(&outs[i].array);
+        if (out_schemas[i].release) out_schemas[i].release(&out_schemas[i]);
+      }
+      throw;
+    }
+  });
+}
+
 namespace {
 struct ParquetImageHolder { chq::ParquetImage img; };
 void release_parquet_image(chq_parquet_image* m) {

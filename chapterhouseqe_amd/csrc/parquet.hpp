@@ -85,6 +85,8 @@ struct Batch;
 struct Buffer;
 // One row group decoded into a device-resident batch (parquet_scan.cpp + parquet.hip).
 Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group);
+// Several consecutive row groups, one batch each: their decodes overlap, the host synchronises twice per call
+std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int first, int count);
 
 // One record batch -> one complete Parquet file (one row group) in host memory (parquet_write.cpp + parquet_write.hip).
 struct ParquetImage {

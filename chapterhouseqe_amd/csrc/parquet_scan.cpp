@@ -66,22 +66,28 @@ struct ColumnWork {
 
 }  // namespace
 
-Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
+namespace {
+struct RowGroupJob {   // one row group between its two phases
+  int64_t rows = 0;
+  std::vector<ColumnWork> work;
+  BufferPtr scal;                 // Scalars per column, on the device
+  std::vector<Scalars> hs;        // ... and read back
+};
+
+// ---- phase A: everything up to the Utf8 offsets, the columns side by side on the auxiliary streams (already forked) -----
+void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, size_t stream_shift) {
   if (row_group < 0 || row_group >= (int)f.row_groups.size()) malformed("row group " + std::to_string(row_group) + " of " + std::to_string(f.row_groups.size()));
   const PqRowGroup& rg = f.row_groups[row_group];
   const int64_t rows = rg.num_rows;
   if (rows < 0 || rows >= (1ll << 31)) unsupported("row group of " + std::to_string(rows) + " rows");
   const size_t nc = f.columns.size();
-  std::vector<ColumnWork> work(nc);
-  DrainOnUnwind drain{ctx};   // (declared after `work`: runs before the buffers are released)
-  auto scal = make_device_buffer(sizeof(Scalars) * (nc + 1), ctx.device);
-  check_hip(hipMemsetAsync(scal->ptr, 0, sizeof(Scalars) * (nc + 1), ctx.stream), "memset");
-  Scalars* dscal = (Scalars*)scal->ptr;
-
-  // ---- phase A: everything up to the Utf8 offsets, the columns side by side on their own streams -----------------------
-  fork_streams(ctx);
+  job.rows = rows;
+  job.work.assign(nc, ColumnWork{});
+  std::vector<ColumnWork>& work = job.work;
+  job.hs.assign(nc + 1, Scalars{});
+  Scalars* dscal = (Scalars*)job.scal->ptr;   // (allocated and zeroed by the caller, on ctx.stream, before the streams forked)
   for (size_t ci = 0; ci < nc; ++ci) {
-    const hipStream_t cstream = ctx.aux[ci % Context::kAuxStreams];
+    const hipStream_t cstream = ctx.aux[(ci + stream_shift) % Context::kAuxStreams];
     const PqColumnSchema& cs = f.columns[ci];
     const PqColumnChunk& cc = rg.columns[ci];
     ColumnWork& w = work[ci];
@@ -232,18 +238,19 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
       }
     }
   }
-  join_streams(ctx);
-  std::vector<Scalars> hs(nc + 1);
-  check_hip(hipMemcpyAsync(hs.data(), scal->ptr, sizeof(Scalars) * nc, hipMemcpyDeviceToHost, ctx.stream), "read back");
-  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+}
 
-  // ---- phase B: per-row outputs ---------------------------------------------------------------------------------------
+// ---- phase B: per-row outputs (sizes are on the host now) -----------------------------------------------------------------
+Batch phase_b(Context& ctx, RowGroupJob& job, size_t stream_shift) {
+  const int64_t rows = job.rows;
+  const size_t nc = job.work.size();
+  std::vector<ColumnWork>& work = job.work;
+  const std::vector<Scalars>& hs = job.hs;
   Batch out;
   out.on_device = true; out.device_id = ctx.device; out.nrows = rows;
   const int grid = ctx.num_cus * 8;
-  fork_streams(ctx);
   for (size_t ci = 0; ci < nc; ++ci) {
-    const hipStream_t cstream = ctx.aux[ci % Context::kAuxStreams];
+    const hipStream_t cstream = ctx.aux[(ci + stream_shift) % Context::kAuxStreams];
     ColumnWork& w = work[ci];
     if (hs[ci].err) malformed(std::string(hs[ci].err == PQ_ERR_LEVELS ? "definition levels" : "values") + " of column '" + w.schema->name + "' are malformed");
     Column o;
@@ -294,9 +301,53 @@ Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
     }
     out.cols.push_back(std::move(o));
   }
-  join_streams(ctx);
-  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the temporaries of `work` are released on return
   return out;
+}
+}  // namespace
+
+// Row groups [first, first + count): phase A of all of them is in flight before the first size is read back, so the two
+// host synchronisations are paid once per call (per wave of about 1 GiB of column chunks), not once per row group, and the
+// upload of one row group overlaps the decode of the previous ones.
+std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int first, int count) {
+  if (first < 0 || count < 0 || first + count > (int)f.row_groups.size())
+    malformed("row groups [" + std::to_string(first) + ", " + std::to_string(first + count) + ") of " + std::to_string(f.row_groups.size()));
+  std::vector<Batch> outs;
+  outs.reserve((size_t)count);
+  int next = first;
+  while (next < first + count) {
+    int wave_end = next;
+    int64_t wave_bytes = 0;
+    while (wave_end < first + count) {   // a wave: about 1 GiB of column chunks resident at once (at least one row group)
+      int64_t b = 0;
+      for (const PqColumnChunk& c : f.row_groups[(size_t)wave_end].columns) b += c.total_compressed_size;
+      if (wave_end > next && wave_bytes + b > ((int64_t)1 << 30)) break;
+      wave_bytes += b; ++wave_end;
+    }
+    std::vector<RowGroupJob> jobs((size_t)(wave_end - next));
+    DrainOnUnwind drain{ctx};   // (declared after `jobs`: runs before their buffers are released)
+    for (RowGroupJob& job : jobs) {
+      job.scal = make_device_buffer(sizeof(Scalars) * (f.columns.size() + 1), ctx.device);
+      check_hip(hipMemsetAsync(job.scal->ptr, 0, sizeof(Scalars) * (f.columns.size() + 1), ctx.stream), "memset");
+    }
+    fork_streams(ctx);
+    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j);
+    join_streams(ctx);
+    for (RowGroupJob& job : jobs)
+      check_hip(hipMemcpyAsync(job.hs.data(), job.scal->ptr, sizeof(Scalars) * job.work.size(), hipMemcpyDeviceToHost, ctx.stream), "read back");
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+    fork_streams(ctx);
+    for (size_t j = 0; j < jobs.size(); ++j) outs.push_back(phase_b(ctx, jobs[j], j));
+    join_streams(ctx);
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the temporaries of `jobs` are released here
+    next = wave_end;
+  }
+  return outs;
+}
+
+Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group) {
+  if (row_group < 0 || row_group >= (int)f.row_groups.size()) malformed("row group " + std::to_string(row_group) + " of " + std::to_string(f.row_groups.size()));
+  std::vector<Batch> one = parquet_read_row_groups(ctx, f, row_group, 1);
+  return std::move(one[0]);
 }
 
 }  // namespace chq

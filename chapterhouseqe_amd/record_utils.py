@@ -484,6 +484,25 @@ class ParquetFile:
                                                 C.byref(out.array), C.byref(out.schema))
         return _finish(ctx, rc, out, device_result)
 
+    def read_row_groups(self, first: int = 0, count: Optional[int] = None, *, ctx: Optional[Context] = None, device_result: bool = True):
+        """Row groups [first, first + count) as one batch each (`chq_parquet_read_row_groups`): decoded together, two host
+        synchronisations per call."""
+        ctx = ctx or default_context()
+        n = self.num_row_groups - first if count is None else count
+        outs = (L.ArrowDeviceArray * max(n, 1))()
+        schemas = (L.ArrowSchema * max(n, 1))()
+        rc = L.lib().chq_parquet_read_row_groups(ctx.handle, self._h, first, n, L.ARROW_DEVICE_ROCM if device_result else L.ARROW_DEVICE_CPU,
+                                                 outs, schemas)
+        if rc:
+            raise ChqError(rc, ctx.last_error())
+        res = []
+        for i in range(n):
+            cb = _CBatch()   # struct copy = Arrow "move"
+            C.memmove(C.addressof(cb.array), C.addressof(outs[i]), C.sizeof(L.ArrowDeviceArray))
+            C.memmove(C.addressof(cb.schema), C.addressof(schemas[i]), C.sizeof(L.ArrowSchema))
+            res.append(_finish(ctx, 0, cb, device_result))
+        return res
+
     def close(self) -> None:
         if self._h:
             L.lib().chq_parquet_close(self._h)
@@ -518,8 +537,8 @@ def scan_parquet(source, *, ctx: Optional[Context] = None, device_result: bool =
     """Every row group of a Parquet file as one batch each, decoded on the GPU (generator)."""
     f = ParquetFile(source)
     try:
-        for i in range(f.num_row_groups):
-            yield f.read_row_group(i, ctx=ctx, device_result=device_result)
+        for batch in f.read_row_groups(ctx=ctx, device_result=device_result):
+            yield batch
     finally:
         f.close()
 

@@ -287,6 +287,11 @@ chq_status chq_parquet_describe(const chq_parquet* pq, char* buf, size_t buf_len
 /* Decode one row group.  `out_device`: ARROW_DEVICE_ROCM (stays in HBM) or ARROW_DEVICE_CPU (copied down). */
 chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32_t row_group, int out_device,
                                       struct ArrowDeviceArray* out, struct ArrowSchema* out_schema);
+/* Row groups [first, first + count), one batch each in outs[i] / out_schemas[i]: all of them are in flight together (the
+ * upload of one overlaps the decode of the others) and the host synchronises twice per call instead of twice per row
+ * group.  On failure nothing is returned. */
+chq_status chq_parquet_read_row_groups(chq_ctx* ctx, const chq_parquet* pq, int32_t first, int32_t count, int out_device,
+                                       struct ArrowDeviceArray* outs, struct ArrowSchema* out_schemas);
 
 /* ---- Parquet write with the page encode on the GPU ---------------------------------------
  * Replaces the encode the reference does with the `parquet` crate behind project_record

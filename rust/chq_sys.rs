@@ -200,6 +200,10 @@ extern "C" {
         ctx: *mut chq_ctx, pq: *const chq_parquet, row_group: i32, out_device: c_int,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,
     ) -> c_int;
+    pub fn chq_parquet_read_row_groups(
+        ctx: *mut chq_ctx, pq: *const chq_parquet, first: i32, count: i32, out_device: c_int,
+        outs: *mut ArrowDeviceArray, out_schemas: *mut FFI_ArrowSchema,
+    ) -> c_int;
     /// one record batch -> one Parquet file image in host memory, pages encoded on the GPU (materialize_files_task.rs:128-141)
     pub fn chq_record_to_parquet(
         ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema, out: *mut chq_parquet_image,

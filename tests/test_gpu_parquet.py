@@ -215,3 +215,22 @@ def test_damaged_pages_are_reported_not_decoded_into_garbage_addresses(ctx):
                 assert e.code in (22, 30), str(e)
                 reported += 1
     assert reported >= 3
+
+
+def test_row_groups_read_together_equal_row_groups_read_one_by_one(ctx):
+    t = sample_table(23_000, seed=61, nulls=True)
+    raw = write_bytes(t, row_group_size=3000, data_page_size=2048)
+    f = chq.ParquetFile(raw)
+    one = [f.read_row_group(i, ctx=ctx).to_host() for i in range(f.num_row_groups)]
+    for first, count in [(0, None), (2, 3), (7, 1), (f.num_row_groups, 0)]:
+        got = f.read_row_groups(first, count, ctx=ctx)
+        n = f.num_row_groups - first if count is None else count
+        assert len(got) == n
+        for k, g in enumerate(got):
+            assert g.to_host().equals(one[first + k])
+    host = f.read_row_groups(ctx=ctx, device_result=False)
+    assert all(h.equals(o) for h, o in zip(host, one))
+    with pytest.raises(chq.ChqError):
+        f.read_row_groups(5, 100, ctx=ctx)
+    assert pa.Table.from_batches(one).equals(pq.read_table(io.BytesIO(raw)).combine_chunks()) or \
+        pa.Table.from_batches(one).combine_chunks().equals(pq.read_table(io.BytesIO(raw)).combine_chunks())
