@@ -49,8 +49,7 @@ for it in range(4):
     f = chq.ParquetFile(raw)
     out_bytes = rows = 0
     first = None
-    for g in range(f.num_row_groups):
-        dev = f.read_row_group(g, ctx=ctx)
+    for dev in f.read_row_groups(ctx=ctx):      # every row group decoded in one call (their uploads and decodes overlap)
         res = chq.filter_project_record(sel.selection, sel.projection, dev, [[], [], []], ctx=ctx)
         image = chq.record_to_parquet(res, ctx=ctx)
         out_bytes += len(image); rows += res.num_rows

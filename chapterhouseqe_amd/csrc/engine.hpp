@@ -134,9 +134,9 @@ struct Context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // Parquet scan: the columns of a row group decode side by side (their per-page kernels are latency-bound, one wave per
   // page); created on first use, joined back into `stream` before anything is read back
-  static constexpr int kAuxStreams = 4;
-  hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kAuxStreams = 12;
+  hipStream_t aux[kAuxStreams] = {};
+  hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {};
   // reusable device scratch
   BufferPtr small;          // [Scratch header (512 B)] [status words of the chained scan]: cleared by ONE memset per call
   size_t small_tiles = 0;   // status words the block has room for

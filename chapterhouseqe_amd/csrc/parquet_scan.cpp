@@ -330,13 +330,13 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       check_hip(hipMemsetAsync(job.scal->ptr, 0, sizeof(Scalars) * (f.columns.size() + 1), ctx.stream), "memset");
     }
     fork_streams(ctx);
-    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j);
+    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j * f.columns.size());
     join_streams(ctx);
     for (RowGroupJob& job : jobs)
       check_hip(hipMemcpyAsync(job.hs.data(), job.scal->ptr, sizeof(Scalars) * job.work.size(), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
     fork_streams(ctx);
-    for (size_t j = 0; j < jobs.size(); ++j) outs.push_back(phase_b(ctx, jobs[j], j));
+    for (size_t j = 0; j < jobs.size(); ++j) outs.push_back(phase_b(ctx, jobs[j], j * f.columns.size()));
     join_streams(ctx);
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the temporaries of `jobs` are released here
     next = wave_end;
