@@ -515,9 +515,34 @@ class ParquetFile:
             pass
 
 
-def record_to_parquet(record: Record, *, ctx: Optional[Context] = None) -> bytes:
+class ParquetImage:
+    """The file image of `record_to_parquet(..., copy=False)`: `view` is a memoryview over the library's host buffer (no
+    copy); `release()` hands the buffer back."""
+
+    def __init__(self, img):
+        self._img = img
+        self.view = memoryview((C.c_uint8 * img.len).from_address(img.data)).cast("B") if img.len else memoryview(b"")
+
+    def __len__(self):
+        return self._img.len if self._img is not None else 0
+
+    def release(self) -> None:
+        if self._img is not None and self._img.release:
+            self.view = memoryview(b"")
+            C.CFUNCTYPE(None, C.c_void_p)(self._img.release)(C.addressof(self._img))
+        self._img = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def record_to_parquet(record: Record, *, ctx: Optional[Context] = None, copy: bool = True):
     """One record batch (host or device resident) -> the bytes of one Parquet file with one row group, pages encoded on the
-    GPU (`chq_record_to_parquet`; what materialize_files_task.rs:128-141 does with the parquet crate on the CPU)."""
+    GPU (`chq_record_to_parquet`; what materialize_files_task.rs:128-141 does with the parquet crate on the CPU).
+    `copy=False` returns a `ParquetImage` over the library's own buffer instead of a `bytes` copy."""
     ctx, src, own_src, _ = _prepare(record, ctx)
     img = L.ParquetImage()
     try:
@@ -527,6 +552,8 @@ def record_to_parquet(record: Record, *, ctx: Optional[Context] = None) -> bytes
             src.release()
     if rc:
         raise ChqError(rc, ctx.last_error())
+    if not copy:
+        return ParquetImage(img)
     try:
         return C.string_at(img.data, img.len)
     finally:

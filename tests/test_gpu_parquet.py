@@ -234,3 +234,12 @@ def test_row_groups_read_together_equal_row_groups_read_one_by_one(ctx):
         f.read_row_groups(5, 100, ctx=ctx)
     assert pa.Table.from_batches(one).equals(pq.read_table(io.BytesIO(raw)).combine_chunks()) or \
         pa.Table.from_batches(one).combine_chunks().equals(pq.read_table(io.BytesIO(raw)).combine_chunks())
+
+
+def test_file_image_without_a_copy(ctx):
+    rec = sample_table(5000, seed=71, nulls=True).to_batches()[0]
+    img = chq.record_to_parquet(rec, ctx=ctx, copy=False)
+    assert len(img) == len(img.view) > 8 and bytes(img.view[:4]) == b"PAR1" and bytes(img.view[-4:]) == b"PAR1"
+    assert pq.read_table(io.BytesIO(bytes(img.view))).to_batches()[0].equals(rec)
+    img.release()
+    assert len(img) == 0
