@@ -232,7 +232,7 @@ __global__ __launch_bounds__(PQ_HYB_BLOCK) void pq_bool_rle_kernel(const PqDecod
 // SPECULATIVE: with L the length found at the current position, lane l looks at position + l * (4 + L) and checks that
 // the length prefix there is L too; the lanes up to the first disagreement are confirmed together (each one's position
 // follows from its predecessor's length).  Columns of equal-length strings (keys, codes, hashes, the reference's sample
-// data) advance 256 values per step (four positions per lane), ragged ones at least one.
+// data) advance 256 values per step (four positions per lane); ragged ones fall back to bursts of plain serial steps.
 constexpr int PQ_WALK_WINDOW = 32768;   // bytes
 constexpr int PQ_WALK_SPEC = 4;         // speculative positions per lane and step
 constexpr int PQ_WALK_BLOCK = 256;      // all four waves stage the window (8 x 16 bytes per thread, in flight together); wave 0 walks
@@ -296,6 +296,18 @@ __global__ __launch_bounds__(PQ_WALK_BLOCK) void pq_ba_walk_kernel(const PqDecod
         }
         k += total;
         q += total * (4u + L);
+        if (total == 1) {   // ragged strings: the speculation bought nothing -- a burst of plain serial steps (uniform scalar
+          // work, broadcast LDS reads, lane 0 stores) before it is tried again: 3 x the rate of one speculative step per value
+          for (int burst = 0; burst < 48 && k < n; ++burst) {
+            if (q + 4 > end) { failed = true; break; }
+            if (q + 4 > wbase + wbytes) break;
+            const uint32_t L2 = length_at(q);
+            if (L2 > end - q - 4) { failed = true; break; }
+            if (lane == 0) { osrc[k] = q + 4; olen[k] = L2; }
+            ++k; q += 4u + L2;
+          }
+          if (failed) break;
+        }
       }
       if (lane == 0) { s_state[0] = q; s_state[1] = k; s_state[2] = failed; }
     }
