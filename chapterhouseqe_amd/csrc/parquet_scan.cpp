@@ -61,6 +61,7 @@ struct ColumnWork {
   int64_t rows = 0;
   BufferPtr chunkb, pages, nonnull, value_base, valid8, row_val, dense, vsrc, vlen, dict_src, dict_len, offsets, block_sums;
   std::vector<BufferPtr> keep;   // page lists: alive until the stream has run
+  std::vector<std::vector<uint32_t>> host_keep;
   int64_t host_values = 0;    // non-null values when known on the host (no levels)
 };
 
@@ -198,10 +199,24 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       w.vlen = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
       p.vsrc = (uint32_t*)w.vsrc->ptr; p.vlen = (uint32_t*)w.vlen->ptr;
       if (!dict_list.empty()) {
-        w.dict_src = make_device_buffer((size_t)dict_count * 4 + 64, ctx.device);
-        w.dict_len = make_device_buffer((size_t)dict_count * 4 + 64, ctx.device);
+        // The dictionary page is ONE page: on the GPU a single workgroup would walk its length prefixes (5 ms for 1 MB of
+        // ragged strings).  The host has the bytes and walks them in ~0.2 ms while it prepares the launches.
+        std::vector<uint32_t> h_src(dict_count), h_len(dict_count);
+        {
+          const uint8_t* dp = f.data + first + dict_at;
+          uint64_t pos = 0;
+          for (uint32_t i = 0; i < dict_count; ++i) {
+            if (pos + 4 > dict_len) malformed("dictionary page of column '" + cs.name + "' ends inside an entry");
+            uint32_t l; memcpy(&l, dp + pos, 4);
+            if ((uint64_t)l > dict_len - pos - 4) malformed("dictionary entry of column '" + cs.name + "' runs past its page");
+            h_src[i] = dict_at + (uint32_t)pos + 4; h_len[i] = l;
+            pos += 4 + (uint64_t)l;
+          }
+        }
+        w.dict_src = upload(ctx, cstream, h_src);
+        w.dict_len = upload(ctx, cstream, h_len);
+        w.host_keep.push_back(std::move(h_src)); w.host_keep.push_back(std::move(h_len));   // (pageable upload sources: alive until the stream ran)
         p.dict_src = (uint32_t*)w.dict_src->ptr; p.dict_len_out = (uint32_t*)w.dict_len->ptr;
-        if (dict_count > 0) { p.walk_dictionary = 1; check_hip(pq_launch_ba_walk(p, 1, cstream), "launch pq_ba_walk_kernel (dictionary)"); p.walk_dictionary = 0; }
         p.page_list = (const int32_t*)dict_dev->ptr;
         check_hip(pq_launch_dict_ba(p, (int)dict_list.size(), cstream), "launch pq_dict_ba_kernel");
       }
