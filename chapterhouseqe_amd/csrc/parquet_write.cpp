@@ -120,7 +120,10 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
     ColumnPlan& pl = plan[ci];
     PwParams& e = pl.enc;
     if (rows == 0) { pl.stream_bytes = 0; }
-    else if (!pl.needs_scan) { pl.stream = e.values; pl.stream_bytes = rows * (int64_t)c.width; }   // the Arrow buffer is the stream
+    else if (!pl.needs_scan) {   // the Arrow buffer is the stream
+      pl.stream = e.values; pl.stream_bytes = rows * (int64_t)c.width;
+      if (pl.stream_bytes >= (1ll << 31) - 64) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: column '" + c.name + "' needs a page of " + std::to_string(pl.stream_bytes) + " bytes"};
+    }
     else {
       const int64_t bytes = (int64_t)h_tot[ci];
       if (bytes >= (1ll << 31) - 64) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: column '" + c.name + "' needs a page of " + std::to_string(bytes) + " bytes"};
