@@ -245,14 +245,17 @@ class MaterializeFilesTask:
         import pyarrow.parquet as pq
         if isinstance(proj_rec, record_utils.DeviceRecordBatch):
             try:
-                image = record_utils.record_to_parquet(proj_rec, ctx=self._ctx)
+                image = record_utils.record_to_parquet(proj_rec, ctx=self._ctx, copy=False)
             except record_utils.ChqError as e:
                 if e.code != 30:   # NotSupported: a type outside Int32/Int64/Float32/Float64/Boolean/Utf8
                     raise
                 proj_rec = proj_rec.to_host()
             else:
-                with open(path, "wb") as f:
-                    f.write(image)
+                try:
+                    with open(path, "wb") as f:
+                        f.write(image.view)     # straight out of the library's host buffer
+                finally:
+                    image.release()
                 return
         pq.write_table(pa.Table.from_batches([proj_rec]), path)
 
