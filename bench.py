@@ -104,7 +104,8 @@ def launcher_selftest(args):
 def extra_lines(chq, torch, dev, ctx, n):
     """Secondary workloads carried by the same driver run (N = 1): BASELINE config 3 (compound predicate over five mixed
     Int32 / Float32 columns + the arithmetic projection of the survivors) and the reference's own schema in its own batch
-    size (id:Int32, value1:Utf8(8), value2:Float32; 10 000-row batches resident in HBM, one group call)."""
+    size (id:Int32, value1:Utf8(8), value2:Float32; 10 000-row batches resident in HBM, one group call), and the rows either
+    side of the path: Parquet scan -> filter + project -> Parquet write on the device."""
     from chapterhouseqe_amd.sqlparse import parse_expr, parse_select
     out = {}
     g = torch.Generator(device=dev); g.manual_seed(3)
@@ -172,7 +173,7 @@ def extra_lines(chq, torch, dev, ctx, n):
         alg = m * (4 + 4 + L8 + 4) + kept * (4 + 4 + L8 + 4)
         out["reference_schema_group"] = {
             "workload": f"{nb} x {rpb}-row batches of id:Int32, value1:Utf8(8), value2:Float32 resident in HBM, WHERE id % 2 = 0, "
-                        "ONE chq_filter_records_coalesced call (device-side join + single-batch kernels)",
+                        "ONE chq_filter_records_coalesced call (one launch over the batches as they lie)",
             "rows": m, "rows_out": kept, "call_ms": call_ms, "rows_per_s": m / (call_ms * 1e-3), "us_per_batch": call_ms * 1e3 / nb,
             "per_batch_call_us": loop_us, "speedup_vs_per_batch_calls": loop_us * nb / (call_ms * 1e3),
             "algorithmic_GBps": alg / (call_ms * 1e-3) / 1e9}
@@ -180,6 +181,55 @@ def extra_lines(chq, torch, dev, ctx, n):
         del devs, ids, chars, v2
     except Exception as err:  # noqa: BLE001
         out["reference_schema_group"] = {"error": repr(err)}
+    try:   # ---- the rows either side of the path: Parquet scan -> filter + project -> Parquet write, every stage on the device ----
+        import io
+        import numpy as np
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        import pyarrow.parquet as pq
+        rows = 8_000_000
+        rng = np.random.default_rng(0)
+        letters = rng.integers(ord("a"), ord("z") + 1, (rows, 8), dtype=np.uint8)
+        value1 = pa.Array.from_buffers(pa.utf8(), rows, [None, pa.py_buffer((np.arange(rows + 1, dtype=np.int32) * 8).tobytes()), pa.py_buffer(letters.tobytes())])
+        t = pa.table({"id": pa.array(np.arange(rows, dtype=np.int32)), "value1": value1, "value2": pa.array((rng.random(rows) * 100).astype(np.float32))})
+        sink = io.BytesIO()
+        pq.write_table(t, sink, compression="none", row_group_size=1 << 20, data_page_size=1 << 20)   # the reference's writer settings
+        raw = sink.getvalue()
+        sel = parse_select("select id, value1, value2 * 2.0 as twice from t where value2 > 10.0")
+        t0 = time.perf_counter(); host_tab = pq.read_table(io.BytesIO(raw)); host_read_ms = (time.perf_counter() - t0) * 1e3
+        best, stages, kept_rows, out_bytes = 1e9, None, 0, 0
+        for it in range(4):
+            t0 = time.perf_counter()
+            f = chq.ParquetFile(raw)
+            devs = f.read_row_groups(ctx=ctx)
+            t1 = time.perf_counter()
+            kept_rows = out_bytes = 0
+            tf = tw = 0.0
+            for d in devs:
+                a = time.perf_counter()
+                res = chq.filter_project_record(sel.selection, sel.projection, d, [[], [], []], ctx=ctx)
+                b = time.perf_counter()
+                img = chq.record_to_parquet(res, ctx=ctx, copy=False)
+                if it == 0 and kept_rows == 0:   # parity of the first result file: pyarrow reads it back
+                    back = pq.read_table(io.BytesIO(bytes(img.view)))
+                    m0 = host_tab.slice(0, d.num_rows).filter(pc.greater(host_tab["value2"].slice(0, d.num_rows), pa.scalar(10.0, pa.float32())))
+                    assert back.num_rows == m0.num_rows and back["id"].combine_chunks().equals(m0["id"].combine_chunks()) and \
+                        back["value1"].combine_chunks().equals(m0["value1"].combine_chunks())
+                out_bytes += len(img); kept_rows += res.num_rows
+                img.release(); res.release(); d.release()
+                tf += b - a; tw += time.perf_counter() - b
+            f.close()
+            total = time.perf_counter() - t0
+            if total < best:
+                best, stages = total, {"scan_ms": (t1 - t0) * 1e3, "filter_project_ms": tf * 1e3, "write_ms": tw * 1e3}
+        out["parquet_pipeline"] = {
+            "workload": f"{rows} rows of id:Int32, value1:Utf8(8), value2:Float32 in an uncompressed Parquet file ({len(raw) / 1e6:.0f} MB, 1 Mi-row row groups) -> "
+                        "chq_parquet_read_row_groups -> chq_filter_project_record (value2 > 10.0; id, value1, value2 * 2.0) -> chq_record_to_parquet",
+            "call_ms": best * 1e3, "input_rows_per_s": rows / best, "rows_out": kept_rows, "file_bytes_out": out_bytes, **stages,
+            "pyarrow_read_only_ms_on_this_host": host_read_ms}
+        del t, value1, letters, raw, host_tab
+    except Exception as err:  # noqa: BLE001
+        out["parquet_pipeline"] = {"error": repr(err)}
     ctx.set_option("trim_pool", 1); torch.cuda.empty_cache()
     return out
 

@@ -18,7 +18,10 @@ BufferPtr upload(Context& ctx, hipStream_t stream, const std::vector<T>& v) {
   return b;
 }
 
-// the columns' streams: forked off ctx.stream, joined back into it
+// the columns' streams: they start behind everything already queued on ctx.stream and are waited for before ctx.stream
+// goes on.  Both ends synchronise on the HOST (every caller synchronises right behind a join anyway): events recorded on /
+// waited for by the context's stream fault when that stream is one of HIP's special handles -- torch's default stream is
+// hipStreamLegacy -- which is what a caller-provided stream may well be.
 void fork_streams(Context& ctx) {
   if (!ctx.aux_fork) {
     check_hip(hipEventCreateWithFlags(&ctx.aux_fork, hipEventDisableTiming), "hipEventCreate");
@@ -27,8 +30,10 @@ void fork_streams(Context& ctx) {
       check_hip(hipEventCreateWithFlags(&ctx.aux_join[i], hipEventDisableTiming), "hipEventCreate");
     }
   }
-  check_hip(hipEventRecord(ctx.aux_fork, ctx.stream), "hipEventRecord");
-  for (int i = 0; i < Context::kAuxStreams; ++i) check_hip(hipStreamWaitEvent(ctx.aux[i], ctx.aux_fork, 0), "hipStreamWaitEvent");
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+}
+void join_streams(Context& ctx) {
+  for (int i = 0; i < Context::kAuxStreams; ++i) check_hip(hipStreamSynchronize(ctx.aux[i]), "hipStreamSynchronize");
 }
 // an error thrown while columns are in flight: wait for them before their temporaries go back to the pool
 struct DrainOnUnwind {
@@ -39,12 +44,6 @@ struct DrainOnUnwind {
     (void)hipStreamSynchronize(ctx.stream);
   }
 };
-void join_streams(Context& ctx) {
-  for (int i = 0; i < Context::kAuxStreams; ++i) {
-    check_hip(hipEventRecord(ctx.aux_join[i], ctx.aux[i]), "hipEventRecord");
-    check_hip(hipStreamWaitEvent(ctx.stream, ctx.aux_join[i], 0), "hipStreamWaitEvent");
-  }
-}
 
 struct Scalars {   // per column, on the device and read back once per phase
   uint32_t err, total_values;

@@ -243,3 +243,20 @@ def test_file_image_without_a_copy(ctx):
     assert pq.read_table(io.BytesIO(bytes(img.view))).to_batches()[0].equals(rec)
     img.release()
     assert len(img) == 0
+
+
+def test_scan_on_a_context_that_borrows_torchs_default_stream():
+    """bench.py (and any torch caller) hands the library torch's current stream -- on ROCm the special hipStreamLegacy handle;
+    the scan's auxiliary streams must fork from / join into it without stream-to-stream event waits (a segfault once)"""
+    import torch
+    c = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    t = sample_table(30_000, seed=81, nulls=True)
+    raw = write_bytes(t, row_group_size=7000)
+    f = chq.ParquetFile(raw)
+    got = f.read_row_groups(ctx=c)
+    want = pq.ParquetFile(io.BytesIO(raw))
+    for i, g in enumerate(got):
+        assert g.to_host().equals(want.read_row_group(i).to_batches()[0])
+    img = chq.record_to_parquet(got[0], ctx=c)
+    assert pq.read_table(io.BytesIO(img)).to_batches()[0].equals(want.read_row_group(0).to_batches()[0])
+    c.close()
