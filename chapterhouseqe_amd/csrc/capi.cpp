@@ -101,7 +101,14 @@ chq_status chq_ctx_create(int device_id, void* hip_stream, chq_ctx** out) {
     check_hip(hipGetDeviceProperties(&prop, device_id), "hipGetDeviceProperties");
     ctx->c.device = device_id;
     ctx->c.num_cus = prop.multiProcessorCount;
-    if (hip_stream) { ctx->c.stream = (hipStream_t)hip_stream; ctx->c.own_stream = false; }
+    if (hip_stream == (void*)hipStreamLegacy) {
+      // The legacy default stream has two spellings, hipStreamLegacy ((hipStream_t)1) and the null handle; the library
+      // keeps the NULL one.  ROCm 7.2's hipEventRecord stores the handle it was given in the event (guarding its own use
+      // with `handle <= 1`), and hipStreamWaitEvent on such an event checks that field only against NULL before
+      // dereferencing it: an event recorded on hipStreamLegacy makes any later hipStreamWaitEvent read address 0x249
+      // (DESIGN.md section 5.1).  Same stream, no special handle ever reaches an event.
+      ctx->c.stream = nullptr; ctx->c.own_stream = false;
+    } else if (hip_stream) { ctx->c.stream = (hipStream_t)hip_stream; ctx->c.own_stream = false; }
     else { check_hip(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking), "hipStreamCreate"); ctx->c.own_stream = true; }
   });
   if (st != CHQ_OK) { delete ctx; return st; }

@@ -121,6 +121,35 @@ BufferPtr make_host_buffer(size_t bytes) {
   return b;
 }
 
+// The auxiliary streams and their fork / join events: created together, on the context's device, the first time a call
+// needs them (the ONE creation site; `aux_ready` is set only when every object exists, so a failure half way is retried
+// from the first missing object instead of leaving null streams behind a non-null event).
+void ensure_aux_streams(Context& ctx) {
+  if (ctx.aux_ready) return;
+  int current = ctx.device;
+  (void)hipGetDevice(&current);
+  if (current != ctx.device) check_hip(hipSetDevice(ctx.device), "hipSetDevice");
+  if (!ctx.aux_fork) check_hip(hipEventCreateWithFlags(&ctx.aux_fork, hipEventDisableTiming), "hipEventCreate");
+  for (int i = 0; i < Context::kAuxStreams; ++i) {
+    if (!ctx.aux[i]) check_hip(hipStreamCreateWithFlags(&ctx.aux[i], hipStreamNonBlocking), "hipStreamCreate");
+    if (!ctx.aux_join[i]) check_hip(hipEventCreateWithFlags(&ctx.aux_join[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  ctx.aux_ready = true;
+}
+// Work on the auxiliary streams starts behind everything queued on ctx.stream ...
+void fork_aux_streams(Context& ctx) {
+  ensure_aux_streams(ctx);
+  check_hip(hipEventRecord(ctx.aux_fork, ctx.stream), "hipEventRecord(fork)");
+  for (int i = 0; i < Context::kAuxStreams; ++i) check_hip(hipStreamWaitEvent(ctx.aux[i], ctx.aux_fork, 0), "hipStreamWaitEvent(fork)");
+}
+// ... and ctx.stream goes on only behind everything queued on them (no host synchronisation on either end)
+void join_aux_streams(Context& ctx) {
+  for (int i = 0; i < Context::kAuxStreams; ++i) {
+    check_hip(hipEventRecord(ctx.aux_join[i], ctx.aux[i]), "hipEventRecord(join)");
+    check_hip(hipStreamWaitEvent(ctx.stream, ctx.aux_join[i], 0), "hipStreamWaitEvent(join)");
+  }
+}
+
 Context::~Context() {
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
@@ -1202,13 +1231,7 @@ bool filter_record_large_host(Context& ctx, const Batch& rec, const chq_table_al
   int64_t chunk = std::max<int64_t>(1 << 20, ((int64_t)64 << 20) / std::max<int64_t>(1, row_bytes));
   if (ctx.opt_large_host_chunk > 0) chunk = ctx.opt_large_host_chunk;
   chunk = (chunk + 16383) / 16384 * 16384;
-  if (!ctx.aux_fork) {   // the auxiliary streams (created once per context; also used by the Parquet scan)
-    check_hip(hipEventCreateWithFlags(&ctx.aux_fork, hipEventDisableTiming), "hipEventCreate");
-    for (int i = 0; i < Context::kAuxStreams; ++i) {
-      check_hip(hipStreamCreateWithFlags(&ctx.aux[i], hipStreamNonBlocking), "hipStreamCreate");
-      check_hip(hipEventCreateWithFlags(&ctx.aux_join[i], hipEventDisableTiming), "hipEventCreate");
-    }
-  }
+  ensure_aux_streams(ctx);   // (created once per context; also used by the Parquet scan)
   const hipStream_t down = ctx.aux[0];
   Batch out;
   out.on_device = false; out.device_id = -1;

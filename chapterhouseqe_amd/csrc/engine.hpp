@@ -137,6 +137,7 @@ struct Context {
   static constexpr int kAuxStreams = 12;
   hipStream_t aux[kAuxStreams] = {};
   hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {};
+  bool aux_ready = false;           // every auxiliary stream and event exists (ensure_aux_streams)
   // reusable device scratch
   BufferPtr small;          // [Scratch header (512 B)] [status words of the chained scan]: cleared by ONE memset per call
   size_t small_tiles = 0;   // status words the block has room for
@@ -153,6 +154,10 @@ struct Context {
 };
 
 void check_hip(hipError_t e, const char* what);
+// the auxiliary streams of a context: created on first use (one site), forked off / joined back into ctx.stream with events
+void ensure_aux_streams(Context& ctx);
+void fork_aux_streams(Context& ctx);
+void join_aux_streams(Context& ctx);
 
 // Arrow C Data Interface <-> Batch
 Batch import_batch(const ArrowDeviceArray* rec, const ArrowSchema* schema);

@@ -21,6 +21,7 @@ namespace chq {
 hipError_t launch_rebase_offsets(const int32_t* in, int32_t* out, int64_t n_plus_1, hipStream_t stream);
 hipError_t launch_bit_shift_copy(const uint8_t* in, int64_t bit_offset, int64_t nbits, uint32_t* out, hipStream_t stream);
 hipError_t launch_count_bits(const uint8_t* in, int64_t bit_offset, int64_t nbits, unsigned long long* out, hipStream_t stream);
+hipError_t launch_validate_offsets(const int32_t* offs, int64_t n, int64_t data_len, uint32_t* flag, hipStream_t stream);
 
 namespace {
 
@@ -471,16 +472,24 @@ Batch record_from_ipc(Context& ctx, const uint8_t* stream, int64_t stream_len, c
     col.owned.push_back(owned);
     out.cols.push_back(std::move(col));
   }
-  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
-  for (auto& chk : utf8_checks) {   // a kernel must never follow offsets out of the data buffer
-    int32_t ends[2] = {0, 0};
-    if (out_on_device) {
-      check_hip(hipMemcpy(&ends[0], chk.first, 4, hipMemcpyDeviceToHost), "read offsets");
-      check_hip(hipMemcpy(&ends[1], chk.first + n, 4, hipMemcpyDeviceToHost), "read offsets");
-    } else { ends[0] = chk.first[0]; ends[1] = chk.first[n]; }
-    if (ends[0] < 0 || ends[1] < ends[0] || (int64_t)ends[1] > chk.second)
-      throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "Arrow IPC Utf8 offsets point outside the data buffer"};
+  // a kernel must never follow offsets out of the data buffer: EVERY offset is checked (0 <= off[i] <= off[i+1] <= data
+  // length), on the device for a device result -- one small kernel per Utf8 column, one flag word read back with the
+  // synchronisation that was needed anyway -- and by a plain loop for a host result
+  BufferPtr flags;
+  if (out_on_device && !utf8_checks.empty()) {
+    flags = make_device_buffer(16, ctx.device);
+    check_hip(hipMemsetAsync(flags->ptr, 0, 16, ctx.stream), "memset");
+    for (auto& chk : utf8_checks)
+      check_hip(launch_validate_offsets(chk.first, n, chk.second, (uint32_t*)flags->ptr, ctx.stream), "launch validate_offsets_kernel");
   }
+  uint32_t bad = 0;
+  if (flags) check_hip(hipMemcpyAsync(&bad, flags->ptr, 4, hipMemcpyDeviceToHost, ctx.stream), "read back");
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  if (!out_on_device) {
+    for (auto& chk : utf8_checks)
+      for (int64_t i = 0; i < n && !bad; ++i) bad |= chk.first[i] < 0 || chk.first[i + 1] < chk.first[i] || (int64_t)chk.first[i + 1] > chk.second;
+  }
+  if (bad) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "Arrow IPC Utf8 offsets are not monotonic or point outside the data buffer"};
   return out;
 }
 

@@ -2223,7 +2223,22 @@ __global__ __launch_bounds__(256) void count_bits_kernel(const uint8_t* in, int6
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
+// flag |= 1 unless 0 <= offs[i] <= offs[i+1] <= data_len for every i in [0, n): offsets that arrived over the wire are checked
+// completely before any kernel follows them (the reference's arrow StreamReader validates the whole offsets buffer)
+__global__ __launch_bounds__(256) void validate_offsets_kernel(const int32_t* offs, int64_t n, int64_t data_len, uint32_t* flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int32_t a = offs[i], b = offs[i + 1];
+    bad |= a < 0 || b < a || (int64_t)b > data_len;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
 static int ipc_grid(int64_t items) { const int64_t g = (items + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+hipError_t launch_validate_offsets(const int32_t* offs, int64_t n, int64_t data_len, uint32_t* flag, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(validate_offsets_kernel, dim3(ipc_grid(n)), dim3(256), 0, stream, offs, n, data_len, flag);
+  return hipGetLastError();
+}
 hipError_t launch_rebase_offsets(const int32_t* in, int32_t* out, int64_t n_plus_1, hipStream_t stream) {
   hipLaunchKernelGGL(rebase_offsets_kernel, dim3(ipc_grid(n_plus_1)), dim3(256), 0, stream, in, out, n_plus_1);
   return hipGetLastError();

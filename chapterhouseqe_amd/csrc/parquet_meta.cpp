@@ -178,7 +178,11 @@ PqPage read_page_header(const uint8_t* file, int64_t size, int64_t at) {
   }
   if (!typed) bad("page header without a type");
   pg.payload_at = (int64_t)(t.p - file);
-  if (pg.compressed_size < 0 || pg.payload_at + pg.compressed_size > size) bad("page payload runs past the file");
+  // sizes come from an untrusted file: compare by subtraction (a sum with a size near INT64_MAX wraps and passes)
+  if (pg.compressed_size < 0 || pg.compressed_size > size - pg.payload_at) bad("page payload runs past the file");
+  if (pg.uncompressed_size < 0 || pg.uncompressed_size >= (1ll << 31)) bad("page of " + std::to_string(pg.uncompressed_size) + " bytes");
+  if (pg.num_values < 0 || pg.num_values >= (1ll << 31)) bad("page with " + std::to_string(pg.num_values) + " values");
+  if (pg.def_bytes < 0 || pg.rep_bytes < 0) bad("negative level section length");
   return pg;
 }
 
@@ -235,13 +239,17 @@ PqFile parquet_open(const uint8_t* data, int64_t size) {
     for (PqColumnChunk& c : rg.columns) {
       if (c.num_values == 0) continue;   // an empty chunk: writers leave its offsets at 0
       int64_t at = c.first_byte();
+      if (c.num_values < 0) bad("column chunk with a negative value count");
+      if (at < 4 || c.total_compressed_size < 0 || c.total_compressed_size > size - 8 - at) bad("column chunk outside the file");
       const int64_t chunk_end = at + c.total_compressed_size;
-      if (at < 4 || chunk_end > size - 8) bad("column chunk outside the file");
       int64_t values = 0;
       while (at < chunk_end && values < c.num_values) {
-        PqPage pg = read_page_header(data, size, at);
+        PqPage pg = read_page_header(data, chunk_end, at);   // (a page may not run past its chunk either)
         at = pg.payload_at + pg.compressed_size;
-        if (pg.type == PQ_DATA_PAGE || pg.type == PQ_DATA_PAGE_V2) values += pg.num_values;
+        if (pg.type == PQ_DATA_PAGE || pg.type == PQ_DATA_PAGE_V2) {
+          if (pg.num_values > c.num_values - values) bad("page with more values than its chunk has left");
+          values += pg.num_values;
+        }
         c.pages.push_back(pg);
       }
       if (values != c.num_values) bad("pages hold " + std::to_string(values) + " values, the chunk's metadata says " + std::to_string(c.num_values));

@@ -18,29 +18,17 @@ BufferPtr upload(Context& ctx, hipStream_t stream, const std::vector<T>& v) {
   return b;
 }
 
-// the columns' streams: they start behind everything already queued on ctx.stream and are waited for before ctx.stream
-// goes on.  Both ends synchronise on the HOST (every caller synchronises right behind a join anyway): events recorded on /
-// waited for by the context's stream fault when that stream is one of HIP's special handles -- torch's default stream is
-// hipStreamLegacy -- which is what a caller-provided stream may well be.
-void fork_streams(Context& ctx) {
-  if (!ctx.aux_fork) {
-    check_hip(hipEventCreateWithFlags(&ctx.aux_fork, hipEventDisableTiming), "hipEventCreate");
-    for (int i = 0; i < Context::kAuxStreams; ++i) {
-      check_hip(hipStreamCreateWithFlags(&ctx.aux[i], hipStreamNonBlocking), "hipStreamCreate");
-      check_hip(hipEventCreateWithFlags(&ctx.aux_join[i], hipEventDisableTiming), "hipEventCreate");
-    }
-  }
-  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
-}
-void join_streams(Context& ctx) {
-  for (int i = 0; i < Context::kAuxStreams; ++i) check_hip(hipStreamSynchronize(ctx.aux[i]), "hipStreamSynchronize");
-}
+// the columns' streams: forked off ctx.stream and joined back into it with events (engine.cpp: fork_aux_streams /
+// join_aux_streams).  Round 2 synchronised on the host instead, after a segfault whose cause is now known: the context ran
+// on the handle hipStreamLegacy, and ROCm 7.2's hipStreamWaitEvent dereferences that handle when it finds it in an event
+// (chq_ctx_create now keeps the null spelling of the same stream).
+void fork_streams(Context& ctx) { fork_aux_streams(ctx); }
+void join_streams(Context& ctx) { join_aux_streams(ctx); }
 // an error thrown while columns are in flight: wait for them before their temporaries go back to the pool
 struct DrainOnUnwind {
   Context& ctx;
   ~DrainOnUnwind() {
-    if (!ctx.aux_fork) return;
-    for (int i = 0; i < Context::kAuxStreams; ++i) (void)hipStreamSynchronize(ctx.aux[i]);
+    for (int i = 0; i < Context::kAuxStreams; ++i) if (ctx.aux[i]) (void)hipStreamSynchronize(ctx.aux[i]);
     (void)hipStreamSynchronize(ctx.stream);
   }
 };
@@ -111,6 +99,7 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       default: unsupported("physical type " + std::to_string(cs.type) + " of column '" + cs.name + "'");
     }
     const int64_t first = rows ? cc.first_byte() : 0, csize = rows ? cc.total_compressed_size : 0;
+    if (csize < 0 || first < 0 || csize > f.size - first) malformed("column chunk outside the file");
     if (csize >= (1ll << 32) - 64) unsupported("column chunk of " + std::to_string(csize) + " bytes");
     w.chunkb = make_device_buffer((size_t)csize + 64, ctx.device);
     check_hip(hipMemcpyAsync(w.chunkb->ptr, f.data + first, (size_t)csize, hipMemcpyHostToDevice, cstream), "upload column chunk");
@@ -127,7 +116,7 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
     for (const PqPage& pg : cc.pages) {
       if (pg.compressed_size != pg.uncompressed_size) malformed("uncompressed page whose sizes differ");
       const int64_t rel = pg.payload_at - first;
-      if (rel < 0 || rel + pg.compressed_size > csize) malformed("page outside its column chunk");
+      if (rel < 0 || pg.compressed_size < 0 || pg.compressed_size > csize - rel) malformed("page outside its column chunk");
       if (pg.type == PQ_DICTIONARY_PAGE) {
         if (pg.encoding != PQ_PLAIN && pg.encoding != PQ_PLAIN_DICTIONARY) unsupported("dictionary page encoding " + std::to_string(pg.encoding));
         if (pg.num_values < 0 || pg.num_values >= (1ll << 31)) malformed("dictionary size");
@@ -137,6 +126,7 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       if (pg.type == PQ_INDEX_PAGE) continue;
       if (pg.type != PQ_DATA_PAGE && pg.type != PQ_DATA_PAGE_V2) unsupported("page type " + std::to_string(pg.type));
       PqPageDesc d{};
+      if (pg.num_values < 0 || pg.num_values > rows - row_at) malformed("page of column '" + cs.name + "' holds more rows than the row group has left");
       d.num_rows = (uint32_t)pg.num_values; d.first_row = row_at;
       int64_t at = rel, left = pg.compressed_size;
       if (pg.type == PQ_DATA_PAGE) {

@@ -102,13 +102,10 @@ def send_record(rec: pa.RecordBatch, record_id: int, dst: int, device=None, tabl
     _send_bytes(_envelope({"record_id": record_id, "table_aliases": table_aliases}, record_to_stream(rec)), dst, device)
 
 
-def recv_record(src: int, device=None) -> Tuple[int, pa.RecordBatch]:
+def recv_record(src: int, device=None):
+    """-> (record_id, RecordBatch, table_aliases), like recv_device_record"""
     meta, stream = _open_envelope(_recv_bytes(src, device))
-    recv_record.last_table_aliases = meta.get("table_aliases")
-    return meta["record_id"], stream_to_record(stream)
-
-
-recv_record.last_table_aliases = None
+    return meta["record_id"], stream_to_record(stream), meta.get("table_aliases")
 
 
 def send_device_record(rec, record_id: int, dst: int, table_aliases=None) -> None:
@@ -213,8 +210,7 @@ def receive_into_exchange(ex, srcs: Sequence[int], ctx=None, device=None) -> int
             if kind == 1:
                 record_id, record, aliases = recv_device_record(src, ctx)
             else:
-                record_id, record = recv_record(src, device)
-                aliases = recv_record.last_table_aliases
+                record_id, record, aliases = recv_record(src, device)
             ex.send_record(record_id, record, aliases)
             added += 1
     return added

@@ -45,7 +45,10 @@ class RecordHandler:
         self._lock = threading.Lock()
         self._hb_stop = threading.Event()
         self._hb_thread: Optional[threading.Thread] = None
-        self.heartbeat_errors: List[str] = []
+        self.heartbeat_errors: List[str] = []            # log of every failed beat (diagnostics only)
+        self.max_request_runtime_errors = 25                # per record, heartbeat_handler.rs:83
+        self._hb_error_counts = {}                          # record id -> failed beats of that record's heartbeat
+        self._hb_failed: Optional[RecordHandlerError] = None
 
     # ---- periodic heartbeat of every tracked record (record_handler.rs:167-184, heartbeat_handler.rs:117-189) --------
     def _heartbeat_main(self) -> None:
@@ -55,10 +58,21 @@ class RecordHandler:
             for record_id, idx in beats:
                 try:
                     self.inbound_exchanges[idx].heartbeat(self.operator_id, record_id)
-                except Exception as e:  # noqa: BLE001 -- the reference logs and keeps beating (max 25 runtime errors)
+                except Exception as e:  # noqa: BLE001 -- the reference logs and keeps beating, up to 25 errors PER RECORD
+                    # (heartbeat_handler.rs:119-127: ReachedMaximumNumberOfRequestRuntimeErrorsAllowed ends the handler
+                    # with an error); a record whose heartbeat has given up is no longer protected from being handed to
+                    # a second instance, so the task must fail instead of carrying on: every later call raises
                     self.heartbeat_errors.append(repr(e))
-                    if len(self.heartbeat_errors) >= 25:
-                        return
+                    with self._lock:
+                        n = self._hb_error_counts.get(record_id, 0) + 1
+                        self._hb_error_counts[record_id] = n
+                        if n >= self.max_request_runtime_errors and self._hb_failed is None:
+                            self._hb_failed = RecordHandlerError(
+                                f"reached maximum number of request runtime errors allowed: {n} (heartbeat of record {record_id}; last: {e!r})")
+
+    def _check_heartbeats(self) -> None:
+        if self._hb_failed is not None:
+            raise self._hb_failed
 
     def _track(self, record_id: int, exchange_idx: int) -> None:
         with self._lock:
@@ -77,6 +91,7 @@ class RecordHandler:
     def next_record(self, max_wait_s: Optional[float] = None) -> Optional[ExchangeRecord]:
         """Pull the next record from the FIRST inbound exchange (a producer reads only its first inbound
         exchange, record_handler.rs:133-138). Returns None when the exchange has nothing left."""
+        self._check_heartbeats()
         if not self.inbound_exchanges:
             raise RecordHandlerError("inbound exchanges is empty")
         ex = self.inbound_exchanges[0]
@@ -97,6 +112,7 @@ class RecordHandler:
     def try_next_record(self) -> Optional[ExchangeRecord]:
         """Non-blocking pull: a record that is queued right now, else None (nothing available yet, or nothing left).
         Not in the reference -- the GPU filter task uses it to drain the queue into one batch-group launch."""
+        self._check_heartbeats()
         if not self.inbound_exchanges:
             raise RecordHandlerError("inbound exchanges is empty")
         ex = self.inbound_exchanges[0]
@@ -108,11 +124,13 @@ class RecordHandler:
         return ExchangeRecord(record_id, record, aliases)
 
     def send_record_to_outbound_exchange(self, record_id: int, record: Any, table_aliases: List[List[str]]) -> None:
+        self._check_heartbeats()
         if self.outbound_exchange is None:
             raise RecordHandlerError("outbound exchange is none")
         self.outbound_exchange.send_record(record_id, record, table_aliases)
 
     def complete_record(self, rec: ExchangeRecord) -> None:
+        self._check_heartbeats()
         with self._lock:
             if rec.record_id not in self.tracked_records:
                 raise RecordHandlerError(f"unable to find tracked record: {rec.record_id}")
@@ -121,6 +139,7 @@ class RecordHandler:
         self.inbound_exchanges[idx].operator_completed_record_processing(self.operator_id, rec.record_id)
         with self._lock:
             self.tracked_records.pop(rec.record_id, None)
+            self._hb_error_counts.pop(rec.record_id, None)
 
     def close(self) -> None:
         """cancel every heartbeat (the reference cancels the tracker's token and waits for the tasks)"""

@@ -245,6 +245,37 @@ class DeviceRecordBatch:
             raise ChqError(rc, dst_ctx.last_error())
         return DeviceRecordBatch(dst_ctx, out, keepalive=self)
 
+    # ---- zero-copy torch views of the buffers in HBM (tests, benches, handing a column to RCCL) -------------------------
+    _TORCH_TYPES = {"c": ("int8", 1), "C": ("uint8", 1), "s": ("int16", 2), "i": ("int32", 4), "l": ("int64", 8),
+                    "f": ("float32", 4), "g": ("float64", 8), "e": ("float16", 2)}
+
+    def _hbm_view(self, torch, address: int, nbytes: int):
+        dev = torch.device("cuda", self.ctx.device_id)
+        if nbytes <= 0 or not address:
+            return torch.empty(0, dtype=torch.uint8, device=dev)
+
+        class _Range:   # __cuda_array_interface__ over a raw HBM range; keeps the batch (and so its buffers) alive
+            def __init__(self, owner):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (address, False), "version": 2}
+                self._owner = owner
+        return torch.as_tensor(_Range(self), device=dev)
+
+    def column_tensor(self, i: int, torch):
+        """The values of fixed-width column i (Arrow slice offset applied) as a torch tensor over the same HBM bytes."""
+        arr = self._cb.array.array.children[i].contents
+        fmt = self._cb.schema.children[i].contents.format.decode()
+        name, width = self._TORCH_TYPES[fmt]
+        raw = self._hbm_view(torch, (arr.buffers[1] or 0) + arr.offset * width, arr.length * width)
+        return raw.view(getattr(torch, name))
+
+    def utf8_tensors(self, i: int, torch):
+        """(offsets, data) of Utf8 column i: int32 offsets [length + 1] (slice offset applied, values still absolute) and
+        the uint8 data buffer from byte 0 up to the last offset."""
+        arr = self._cb.array.array.children[i].contents
+        offs = self._hbm_view(torch, (arr.buffers[1] or 0) + arr.offset * 4, (arr.length + 1) * 4).view(torch.int32)
+        end = int(offs[-1].item()) if arr.length >= 0 and offs.numel() else 0
+        return offs, self._hbm_view(torch, arr.buffers[2] or 0, end)
+
     def release(self) -> None:
         self._cb.release()
 

@@ -246,10 +246,13 @@ def test_file_image_without_a_copy(ctx):
 
 
 def test_scan_on_a_context_that_borrows_torchs_default_stream():
-    """bench.py (and any torch caller) hands the library torch's current stream -- on ROCm the special hipStreamLegacy handle;
-    the scan's auxiliary streams must fork from / join into it without stream-to-stream event waits (a segfault once)"""
+    """bench.py (and any torch caller) hands the library torch's current stream, which the binding spells hipStreamLegacy.
+    ROCm 7.2's hipStreamWaitEvent dereferences that handle when it finds it in an event (the round-2
+    segfault); chq_ctx_create keeps the null spelling of the same stream, so the scan's auxiliary streams fork from / join
+    into it with events again"""
     import torch
     c = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    assert c.stream == 0          # the legacy default stream under its null handle: no special handle reaches an event
     t = sample_table(30_000, seed=81, nulls=True)
     raw = write_bytes(t, row_group_size=7000)
     f = chq.ParquetFile(raw)

@@ -181,3 +181,31 @@ def test_config4_100m_rows_as_five_batches_in_one_group():
         del got_ids, got_chars, got_v
         o.release()
     ctx.close()
+
+
+def test_config5_one_rank_shard_at_full_size():
+    """BASELINE config 5 (sample_queries/huge_simple.sql:3-4, 10 B rows over 8 GPUs): ONE rank's 1.25 B-row shard of
+    id:Int32, value1:Utf8(8), value2:Float32 -- 10 GB of string bytes, so ten device batches under the int32 offset limit --
+    through ONE chq_filter_records call (`id % 2 = 0`), exactly as bench.py --config 5 runs it on every GPU.  Every output
+    batch is checked by size-independent properties: exactly the even ids in order, each with its own string and float."""
+    import torch
+
+    import bench
+    dev = torch.device("cuda", 0)
+    ctx = chq.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    rows, batch_rows = 1_250_000_000, 125_000_000
+    batches, keep = bench.build_config5_shard(chq, torch, dev, ctx, rows, batch_rows)
+    assert len(batches) == 10 and sum(b.num_rows for b in batches) == rows
+    grp = chq.RecordGroup(batches, ctx)
+    outs = chq.filter_records(grp, [[], [], []], parse_expr(bench.C5_PREDICATE), ctx=ctx)
+    st = ctx.last_stats()
+    assert len(outs) == 10 and sum(o.num_rows for o in outs) == rows // 2
+    assert st["rows_in"] == rows and st["rows_out"] == rows // 2
+    # 20 B/row read (id, offsets by both phases, float) + the selected strings; 4 + 4 + 8 + 4 B per surviving row written
+    assert st["bytes_read_alg"] >= rows * 16 and st["bytes_written_alg"] >= (rows // 2) * 20
+    for b in range(len(outs)):
+        bench.check_config5_outputs(torch, keep, outs, b)
+    for o in outs:
+        o.release()
+    grp.release()
+    ctx.close()

@@ -239,7 +239,7 @@ def _worker(rank, world, port, tmpdir):
         if rank == 1:
             send_record(outs[mine[0]], mine[0], dst=0)
         else:
-            rid, rec = recv_record(src=1)
+            rid, rec, _aliases = recv_record(src=1)
             assert rid == 1 and rec.equals(O.filter_record(batches[1], [[], [], []], sel.selection))
         dist.barrier()
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
