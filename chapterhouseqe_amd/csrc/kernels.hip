@@ -42,6 +42,18 @@ typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rows_rsrc(const void* col, int64_t w0, int width, int nact) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)col + w0 * width), 0, nact * width, 0x00020000);
 }
+// The lane index behind an optimisation barrier.  Every group of range-checked loads takes its own copy right in front of
+// the loads: `copy + 64 j` then lives in the loads' basic block, where instruction selection folds the constant into the
+// instructions' immediate offset field (one VGPR for all slots).  Without it the compiler shares `lane + 64 j` between all
+// load groups of the kernel, computes the sixteen values once at the top and keeps them -- in every element size -- live
+// across everything: the 192 spilled VGPRs of round 2's PARTIAL instantiations were these.
+__device__ __forceinline__ int opaque_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
+// the lane index recomputed on the spot (two VALU instructions): nothing stays live for it between two uses
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 template <typename TY> __device__ __forceinline__ TY buf_load(__amdgpu_buffer_rsrc_t r, int elem);
 template <> __device__ __forceinline__ uint8_t buf_load<uint8_t>(__amdgpu_buffer_rsrc_t r, int e) { return __builtin_amdgcn_raw_buffer_load_b8(r, e, 0, 0); }
 template <> __device__ __forceinline__ int8_t buf_load<int8_t>(__amdgpu_buffer_rsrc_t r, int e) { return (int8_t)__builtin_amdgcn_raw_buffer_load_b8(r, e, 0, 0); }
@@ -271,9 +283,12 @@ struct Interp {
     } else {
       int64_t rem = nrows - w0;
       nact = rem <= 0 ? 0 : (rem >= 64 * R ? 64 * R : (int)rem);
-      actv = 0;
-#pragma unroll
-      for (int j = 0; j < R; ++j) actv |= (uint32_t)(j * 64 + lane < nact) << j;
+      // slot j is active for this lane iff 64 j + lane < nact: all slots of the complete 64-row groups, plus -- for the lanes
+      // below the remainder -- the slot of the incomplete one (scalar arithmetic and ONE vector compare; sixteen compares of
+      // `lane | 64 j` kept sixteen VGPRs alive from the top of the kernel)
+      const int full = nact >> 6, part = nact & 63;
+      const uint32_t below = full >= 32 ? 0xffffffffu : ((1u << full) - 1u);
+      actv = below | ((lane < part) ? (1u << (full & 31)) : 0u);
     }
   }
   __device__ __forceinline__ void stash_put(int ref_idx, const uint32_t (&v)[R]) {
@@ -303,6 +318,9 @@ struct Interp {
   }
 
   // ---- operand fetch ---------------------------------------------------------------------------
+  // (Every case of the type switches below ends with a store to l[]: the compiler merges the cases' final stores into one
+  // block, and when one of them went to h[] instead the merged store got a pointer phi (l or h), which keeps the whole
+  // interpreter object -- every register array -- in scratch memory: the 152 bytes of scratch of round 2's WIDE kernels.)
   template <bool FULL>
   __device__ __forceinline__ void fetch_values(const ColRef& cr, const void* values, uint32_t (&l)[R], uint32_t (&h)[RH]) {
     struct { int type; const void* values; } c{cr.type, values};
@@ -328,31 +346,32 @@ struct Interp {
         case T_I64: case T_U64: case T_F64:
           if constexpr (WIDE) { const uint2* p = (const uint2*)c.values + w0;
 #pragma unroll
-            for (int j = 0; j < R; ++j) { uint2 x = p[j * 64 + lane]; l[j] = x.x; h[j] = x.y; } }
+            for (int j = 0; j < R; ++j) { uint2 x = p[j * 64 + lane]; h[j] = x.y; l[j] = x.x; } }   // (l[] last, like every other case: see below)
           break;
         default: break;
       }
     } else {
+      const int ol = opaque_lane(lane);
       switch (c.type) {
         case T_I8: { const auto r = wave_rows_rsrc(c.values, w0, 1, nact);
 #pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)buf_load<int8_t>(r, j * 64 + lane); } break;
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)buf_load<int8_t>(r, j * 64 + ol); } break;
         case T_U8: { const auto r = wave_rows_rsrc(c.values, w0, 1, nact);
 #pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = buf_load<uint8_t>(r, j * 64 + lane); } break;
+          for (int j = 0; j < R; ++j) l[j] = buf_load<uint8_t>(r, j * 64 + ol); } break;
         case T_I16: { const auto r = wave_rows_rsrc(c.values, w0, 2, nact);
 #pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)buf_load<int16_t>(r, j * 64 + lane); } break;
+          for (int j = 0; j < R; ++j) l[j] = (uint32_t)(int32_t)buf_load<int16_t>(r, j * 64 + ol); } break;
         case T_U16: { const auto r = wave_rows_rsrc(c.values, w0, 2, nact);
 #pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = buf_load<uint16_t>(r, j * 64 + lane); } break;
+          for (int j = 0; j < R; ++j) l[j] = buf_load<uint16_t>(r, j * 64 + ol); } break;
         case T_I32: case T_U32: case T_F32: { const auto r = wave_rows_rsrc(c.values, w0, 4, nact);
 #pragma unroll
-          for (int j = 0; j < R; ++j) l[j] = buf_load<uint32_t>(r, j * 64 + lane); } break;
+          for (int j = 0; j < R; ++j) l[j] = buf_load<uint32_t>(r, j * 64 + ol); } break;
         case T_I64: case T_U64: case T_F64:
           if constexpr (WIDE) { const auto r = wave_rows_rsrc(c.values, w0, 8, nact);
 #pragma unroll
-            for (int j = 0; j < R; ++j) { uint2 x = buf_load<uint2>(r, j * 64 + lane); l[j] = x.x; h[j] = x.y; } }
+            for (int j = 0; j < R; ++j) { uint2 x = buf_load<uint2>(r, j * 64 + ol); h[j] = x.y; l[j] = x.x; } }
           break;
         default: break;
       }
@@ -421,22 +440,24 @@ struct Interp {
     }
     if (to == C_I32 || to == C_U32) return;   // u8/u16 -> i32: same bits
     if constexpr (WIDE) {
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        uint64_t x;
-        if (to == C_F64) {
-          double d;
-          switch (from) {
-            case C_I32: d = (double)(int32_t)l[j]; break; case C_U32: d = (double)l[j]; break;
-            case C_I64: d = (double)(int64_t)PACK64(l[j], h[j]); break; case C_U64: d = (double)PACK64(l[j], h[j]); break;
-            default: d = (double)__uint_as_float(l[j]); break;
-          }
-          x = (uint64_t)__double_as_longlong(d);
-        } else {  // I64 / U64 from a 32-bit integer class
-          x = from == C_I32 ? (uint64_t)(int64_t)(int32_t)l[j] : (uint64_t)l[j];
+      // (one straight-line loop per source class: with the switch inside the slot loop the compiler kept the loop rolled and
+      // indexed l[] / h[] dynamically -- the interpreter's whole register state then lived in scratch memory)
+#define CVT_LOOP(EXPR)                                                                                  \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) { const uint64_t x = (uint64_t)(EXPR); l[j] = (uint32_t)x; h[j] = (uint32_t)(x >> 32); } }
+      if (to == C_F64) {
+        switch (from) {
+          case C_I32: CVT_LOOP(__double_as_longlong((double)(int32_t)l[j])) break;
+          case C_U32: CVT_LOOP(__double_as_longlong((double)l[j])) break;
+          case C_I64: CVT_LOOP(__double_as_longlong((double)(int64_t)PACK64(l[j], h[j]))) break;
+          case C_U64: CVT_LOOP(__double_as_longlong((double)PACK64(l[j], h[j]))) break;
+          default: CVT_LOOP(__double_as_longlong((double)__uint_as_float(l[j]))) break;
         }
-        l[j] = (uint32_t)x; h[j] = (uint32_t)(x >> 32);
+      } else if (from == C_I32) {   // I64 / U64 from a 32-bit integer class
+        CVT_LOOP((int64_t)(int32_t)l[j])
+      } else {
+        CVT_LOOP((uint64_t)l[j])
       }
+#undef CVT_LOOP
     }
   }
 
@@ -485,8 +506,10 @@ struct Interp {
         case OP_ADD: I32_LOOP(x, y, w = (int64_t)a + b;) break;
         case OP_MUL: I32_LOOP(x, y, w = (int64_t)a * b;) break;
         case OP_SUB: I32_DIR(w = (int64_t)a - b;) break;
-        case OP_DIV: I32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (a == INT32_MIN && b == -1) w = 2147483648LL; else w = a / b;) break;
-        default: I32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (b == -1) { if ((int64_t)a == tlo) BAD(DE_OVERFLOW); w = 0; } else w = a % b;) break;
+        // (the software division is ~40 instructions with a dozen temporaries: one slot at a time -- interleaved over all
+        // sixteen slots by the scheduler it was the peak of the kernel's register pressure)
+        case OP_DIV: I32_DIR(__builtin_amdgcn_sched_barrier(0); if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (a == INT32_MIN && b == -1) w = 2147483648LL; else w = a / b;) break;
+        default: I32_DIR(__builtin_amdgcn_sched_barrier(0); if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else if (b == -1) { if ((int64_t)a == tlo) BAD(DE_OVERFLOW); w = 0; } else w = a % b;) break;
       }
 #undef I32_DIR
 #undef I32_LOOP
@@ -506,8 +529,8 @@ struct Interp {
         case OP_ADD: U32_LOOP(x, y, w = (int64_t)a + b;) break;
         case OP_MUL: U32_LOOP(x, y, { uint64_t pr = (uint64_t)a * b; w = pr > 0x7fffffffffffffffULL ? -1 : (int64_t)pr; }) break;
         case OP_SUB: U32_DIR(w = (int64_t)a - b;) break;
-        case OP_DIV: U32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a / b;) break;
-        default: U32_DIR(if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a % b;) break;
+        case OP_DIV: U32_DIR(__builtin_amdgcn_sched_barrier(0); if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a / b;) break;
+        default: U32_DIR(__builtin_amdgcn_sched_barrier(0); if (b == 0) { BAD(DE_DIV_ZERO); w = 0; } else w = a % b;) break;
       }
 #undef U32_DIR
 #undef U32_LOOP
@@ -542,63 +565,60 @@ struct Interp {
       }
 #undef F32_LOOP
     } else if constexpr (WIDE) {
+      // 64-bit classes: as above, the operator and the operand order are chosen OUTSIDE the slot loops (a switch inside the
+      // unrolled loop made the compiler index the register arrays dynamically, i.e. keep them in scratch memory)
+#define W_LOOP(TY, A, B, BODY)                                                                          \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const TY x = (TY)PACK64(lo[j], hi[j]), y = (TY)PACK64(bl(j), bh(j));                               \
+      const TY a = (A), b = (B);                                                                         \
+      const bool live = (validv >> j) & 1;                                                               \
+      TY w = 0; bool o = false;                                                                          \
+      BODY                                                                                               \
+      if (o) BAD(DE_OVERFLOW);                                                                           \
+      lo[j] = (uint32_t)(uint64_t)w; hi[j] = (uint32_t)((uint64_t)w >> 32); } }
+#define W_DIR(TY, BODY) { if (rev) W_LOOP(TY, y, x, BODY) else W_LOOP(TY, x, y, BODY) }
       if (cls == C_I64) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const long long x = (long long)PACK64(lo[j], hi[j]), y = (long long)PACK64(bl(j), bh(j));
-          const long long a = rev ? y : x, b = rev ? x : y;
-          long long w = 0;
-          const bool live = (validv >> j) & 1;
-          bool o = false;
-          switch (op) {
-            case OP_ADD: o = __builtin_saddll_overflow(a, b, &w); break;
-            case OP_SUB: o = __builtin_ssubll_overflow(a, b, &w); break;
-            case OP_MUL: o = __builtin_smulll_overflow(a, b, &w); break;
-            case OP_DIV: if (b == 0) BAD(DE_DIV_ZERO); else if (a == INT64_MIN && b == -1) o = true; else w = a / b; break;
-            default: if (b == 0) BAD(DE_DIV_ZERO); else if (a == INT64_MIN && b == -1) o = true; else w = a % b; break;
-          }
-          if (o) BAD(DE_OVERFLOW);
-          lo[j] = (uint32_t)(uint64_t)w; hi[j] = (uint32_t)((uint64_t)w >> 32);
+        switch (op) {
+          case OP_ADD: W_LOOP(long long, x, y, o = __builtin_saddll_overflow(a, b, &w);) break;
+          case OP_MUL: W_LOOP(long long, x, y, o = __builtin_smulll_overflow(a, b, &w);) break;
+          case OP_SUB: W_DIR(long long, o = __builtin_ssubll_overflow(a, b, &w);) break;
+          case OP_DIV: W_DIR(long long, if (b == 0) BAD(DE_DIV_ZERO); else if (a == INT64_MIN && b == -1) o = true; else w = a / b;) break;
+          default: W_DIR(long long, if (b == 0) BAD(DE_DIV_ZERO); else if (a == INT64_MIN && b == -1) o = true; else w = a % b;) break;
         }
       } else if (cls == C_U64) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const u64 x = PACK64(lo[j], hi[j]), y = PACK64(bl(j), bh(j));
-          const u64 a = rev ? y : x, b = rev ? x : y;
-          u64 w = 0;
-          const bool live = (validv >> j) & 1;
-          bool o = false;
-          switch (op) {
-            case OP_ADD: o = __builtin_uaddll_overflow(a, b, &w); break;
-            case OP_SUB: o = __builtin_usubll_overflow(a, b, &w); break;
-            case OP_MUL: o = __builtin_umulll_overflow(a, b, &w); break;
-            case OP_DIV: if (b == 0) BAD(DE_DIV_ZERO); else w = a / b; break;
-            default: if (b == 0) BAD(DE_DIV_ZERO); else w = a % b; break;
-          }
-          if (o) BAD(DE_OVERFLOW);
-          lo[j] = (uint32_t)w; hi[j] = (uint32_t)(w >> 32);
+        switch (op) {
+          case OP_ADD: W_LOOP(u64, x, y, o = __builtin_uaddll_overflow(a, b, &w);) break;
+          case OP_MUL: W_LOOP(u64, x, y, o = __builtin_umulll_overflow(a, b, &w);) break;
+          case OP_SUB: W_DIR(u64, o = __builtin_usubll_overflow(a, b, &w);) break;
+          case OP_DIV: W_DIR(u64, if (b == 0) BAD(DE_DIV_ZERO); else w = a / b;) break;
+          default: W_DIR(u64, if (b == 0) BAD(DE_DIV_ZERO); else w = a % b;) break;
         }
       } else if (cls == C_F64) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const double x = __longlong_as_double((long long)PACK64(lo[j], hi[j])), y = __longlong_as_double((long long)PACK64(bl(j), bh(j)));
-          const double a = rev ? y : x, b = rev ? x : y;
-          double w;
-          switch (op) {
-            case OP_ADD: w = a + b; break; case OP_SUB: w = a - b; break; case OP_MUL: w = a * b; break;
-            case OP_DIV: w = a / b; break; default: w = fmod(a, b); break;
-          }
-          if (w != w && a == a && b == b) w = __longlong_as_double((long long)0xFFF8000000000000ULL);   // x86-64 default NaN (see above)
-          if (a != a) w = __longlong_as_double(__double_as_longlong(a) | 0x0008000000000000LL);
-          else if (b != b) w = __longlong_as_double(__double_as_longlong(b) | 0x0008000000000000LL);
-          const uint64_t u = (uint64_t)__double_as_longlong(w);
-          lo[j] = (uint32_t)u; hi[j] = (uint32_t)(u >> 32);
+#define F64_LOOP(A, B, EXPR)                                                                            \
+  { _Pragma("unroll") for (int j = 0; j < R; ++j) {                                                       \
+      const double x = __longlong_as_double((long long)PACK64(lo[j], hi[j])), y = __longlong_as_double((long long)PACK64(bl(j), bh(j))); \
+      const double a = (A), b = (B);                                                                     \
+      double w = (EXPR);                                                                                 \
+      if (w != w && a == a && b == b) w = __longlong_as_double((long long)0xFFF8000000000000ULL);   /* x86-64 default NaN (see above) */ \
+      if (a != a) w = __longlong_as_double(__double_as_longlong(a) | 0x0008000000000000LL);              \
+      else if (b != b) w = __longlong_as_double(__double_as_longlong(b) | 0x0008000000000000LL);         \
+      const uint64_t u = (uint64_t)__double_as_longlong(w);                                              \
+      lo[j] = (uint32_t)u; hi[j] = (uint32_t)(u >> 32); } }
+        switch (op) {
+          case OP_ADD: if (rev) F64_LOOP(y, x, a + b) else F64_LOOP(x, y, a + b) break;   // (operand order decides which NaN propagates)
+          case OP_MUL: if (rev) F64_LOOP(y, x, a * b) else F64_LOOP(x, y, a * b) break;
+          case OP_SUB: if (rev) F64_LOOP(y, x, a - b) else F64_LOOP(x, y, a - b) break;
+          case OP_DIV: if (rev) F64_LOOP(y, x, a / b) else F64_LOOP(x, y, a / b) break;
+          default: if (rev) F64_LOOP(y, x, fmod(a, b)) else F64_LOOP(x, y, fmod(a, b)) break;
         }
+#undef F64_LOOP
       }
+#undef W_DIR
+#undef W_LOOP
     }
 #undef BAD
     // arrow's try_binary / try_unary stop at the first offending valid element: report (node, row, kind)
-    if (__any(errj >= 0)) { if (errj >= 0) report_error(err, ref_order, w0 + 64 * errj + lane, errc); }
+    if (__any(errj >= 0)) { if (errj >= 0) report_error(err, ref_order, w0 + (64 * errj + opaque_lane(lane)), errc); }   // (opaque: the 64-bit `w0 + lane` is not worth a register pair held across the whole program loop)
 #undef bl
 #undef bh
   }
@@ -688,8 +708,9 @@ struct Interp {
       for (int j = 0; j < R; ++j) y[j] = src[j * 64 + lane];
     } else {   // incomplete wave: range-checked loads, rows past the end read as 0 (they are inactive: actv masks them)
       const auto rs = wave_rows_rsrc(vals, w0, 4, nact);
+      const int ol = opaque_lane(lane);
 #pragma unroll
-      for (int j = 0; j < R; ++j) y[j] = nact > 0 ? buf_load<uint32_t>(rs, j * 64 + lane) : 0u;
+      for (int j = 0; j < R; ++j) y[j] = nact > 0 ? buf_load<uint32_t>(rs, j * 64 + ol) : 0u;
     }
   }
 
@@ -826,7 +847,7 @@ struct Interp {
 #undef FAST_I
 #undef FAST_F
       // arrow's try_binary stops at the first offending element: report (node, row, kind) -- as Interp::arith does
-      if (__any(errj >= 0)) { if (errj >= 0) report_error(err, in.ref_order, w0 + 64 * errj + lane, errc); }
+      if (__any(errj >= 0)) { if (errj >= 0) report_error(err, in.ref_order, w0 + (64 * errj + opaque_lane(lane)), errc); }
     }
   }
 
@@ -1021,16 +1042,19 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
   __shared__ uint32_t s_utot[2][NUA];
   __shared__ uint32_t s_ubase[NUA];
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = p.tile_end;                       // this launch: tiles [tile_begin, tile_end)
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ntiles32 = (int)p.tile_end;                    // this launch: tiles [tile_begin, tile_end)
   const int64_t last_tile = (p.nrows + TILE - 1) / TILE - 1;   // of the whole batch
 
+  // Each phase derives its thread / lane index from its own opaque copy: the addresses built from them (LDS slots of the
+  // selection words and the stash, lane byte offsets in every element size) then live inside the phase instead of being
+  // computed once in front of the tile loop and held -- or spilled -- across both phases of every tile.
   auto P = [&](int buf) __attribute__((always_inline)) {   // (two call sites: an outlined copy would take the 2.4 KB parameter block through scratch)
+    const int lane = fresh_lane(), tid = wv * 64 + lane;
     if (tid == 0) s_tile[buf] = p.tile_begin + (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const int64_t tile = uniform64(s_tile[buf]);
-    if (tile >= ntiles) return;
+    if ((int)tile >= ntiles32) return;   // (tile indices fit 32 bits; a 64-bit signed compare of two scalars runs on the VALU and parks a copy of the bound in VGPRs)
     I it;
     int64_t row0 = tile * TILE, nr = p.nrows;
     if constexpr (PARTIAL) {
@@ -1089,9 +1113,10 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           }
         } else if (it.nact > 0) {   // rows [w0, w0 + nact): offsets w0 .. w0 + nact exist, anything past them reads 0
           const auto rs = wave_rows_rsrc(uoffs, it.w0, 4, it.nact + 1);
+          const int ol = opaque_lane(lane);
 #pragma unroll
           for (int j = 0; j < R; ++j) {
-            const uint32_t o = buf_load<uint32_t>(rs, j * 64 + lane), n = buf_load<uint32_t>(rs, j * 64 + lane + 1);
+            const uint32_t o = buf_load<uint32_t>(rs, j * 64 + ol), n = buf_load<uint32_t>(rs, j * 64 + ol + 1);
             bytes += ((selv >> j) & 1) ? n - o : 0u;
           }
         }
@@ -1122,6 +1147,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
   };
 
   auto C = [&](int buf) __attribute__((always_inline)) {
+    const int lane = fresh_lane(), tid = wv * 64 + lane;
     const int64_t tile = uniform64(s_tile[buf]);
     if (wv == 0) {
       u64 excl = 0;
@@ -1201,11 +1227,12 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
       const int32_t* base = (const int32_t*)utf8_ptr(u, 0);
       const int32_t* offs = base + w0;
       const auto rs = wave_rows_rsrc(base, w0, 4, nact + 1);
+      const int ol = opaque_lane(lane);
 #pragma unroll
       for (int jj = 0; jj < CH; ++jj) {
         const uint32_t e = (uint32_t)((j0 + jj) * 64 + lane);
         if (nact == 64 * R) { on[jj] = (uint32_t)offs[e]; nn[jj] = (uint32_t)offs[e + 1]; }
-        else { on[jj] = buf_load<uint32_t>(rs, (int)e); nn[jj] = buf_load<uint32_t>(rs, (int)e + 1); }
+        else { on[jj] = buf_load<uint32_t>(rs, (j0 + jj) * 64 + ol); nn[jj] = buf_load<uint32_t>(rs, (j0 + jj) * 64 + ol + 1); }
       }
     };
     if constexpr (NU > 0) { if (p.n_utf8 > 0) load_offsets(0, 0); }
@@ -1214,10 +1241,11 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
       constexpr bool FULL = decltype(full_tag)::value;
       for (int c = 0; c < ncopy; ++c) {
         const OutCol oc = p.outs[c];
+        const int ol = FULL ? lane : opaque_lane(lane);
         // CH values per lane are loaded (one contiguous 64-element run per instruction), then the selected ones are
         // stored at off0 + (selected rows in earlier slots) + rank of the lane among the selected lanes of its slot
         // complete wave: element j*64+lane off an SGPR base; incomplete wave: range-checked buffer load (0 past the end)
-#define LOADV(TY, src, rs, j) (FULL ? (src)[(j) * 64 + lane] : buf_load<TY>(rs, (j) * 64 + lane))
+#define LOADV(TY, src, rs, j) (FULL ? (src)[(j) * 64 + lane] : buf_load<TY>(rs, (j) * 64 + ol))
 #define COPY_COL(TY, CH)                                                                              \
   { const TY* src = (const TY*)in_ptr(c) + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;        \
     const auto rs = wave_rows_rsrc(in_ptr(c), w0, sizeof(TY), nact);                                    \
@@ -1430,7 +1458,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
   P(0);
   int itn = 0;
   while (true) {
-    if (s_tile[itn & 1] >= ntiles) break;
+    if (__builtin_amdgcn_readfirstlane((int)s_tile[itn & 1]) >= ntiles32) break;
     P((itn + 1) & 1);
     C(itn & 1);
     ++itn;
@@ -1460,16 +1488,16 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
   __shared__ u64 s_base;
   __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t ntiles = p.tile_end;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ntiles32 = (int)p.tile_end;   // (32-bit tile compares and per-phase lane indices: see filter_fused_kernel)
   const int64_t last_tile = (p.nrows + TILE - 1) / TILE - 1;
 
   auto P = [&](int buf) __attribute__((always_inline)) {
+    const int lane = fresh_lane(), tid = wv * 64 + lane;
     if (tid == 0) s_tile[buf] = p.tile_begin + (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const int64_t tile = uniform64(s_tile[buf]);
-    if (tile >= ntiles) return;
+    if ((int)tile >= ntiles32) return;
     I it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
     if constexpr (FASTK) {
@@ -1494,6 +1522,7 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
   };
 
   auto C = [&](int buf) __attribute__((always_inline)) {
+    const int lane = fresh_lane(), tid = wv * 64 + lane;
     const int64_t tile = uniform64(s_tile[buf]);
     if (wv == 0) {
       u64 excl = 0;
@@ -1516,13 +1545,14 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
     // ---- select items that are plain columns: compacting copies --------------------------------------------
     for (int c = 0; c < p.n_copy; ++c) {
       const OutCol oc = p.copies[c];
+      const int ol = opaque_lane(lane);
 #define FCOPY(TY)                                                                                     \
   { const TY* src = (const TY*)oc.in + w0; TY* dst = (TY*)oc.out + off0; unsigned run = 0;            \
     const auto rs = wave_rows_rsrc(oc.in, w0, sizeof(TY), nact);                                       \
     _Pragma("unroll") for (int j0 = 0; j0 < R; j0 += 4) {                                              \
       TY v[4];                                                                                         \
       _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                 \
-        v[jj] = nact == 64 * R ? src[(j0 + jj) * 64 + lane] : buf_load<TY>(rs, (j0 + jj) * 64 + lane); \
+        v[jj] = nact == 64 * R ? src[(j0 + jj) * 64 + lane] : buf_load<TY>(rs, (j0 + jj) * 64 + ol); \
       _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                               \
         const bool sel = (selv >> (j0 + jj)) & 1;                                                      \
         const u64 m = __ballot(sel);                                                                   \
@@ -1567,7 +1597,7 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
   P(0);
   int itn = 0;
   while (true) {
-    if (s_tile[itn & 1] >= ntiles) break;
+    if (__builtin_amdgcn_readfirstlane((int)s_tile[itn & 1]) >= ntiles32) break;
     P((itn + 1) & 1);
     C(itn & 1);
     ++itn;
@@ -1732,10 +1762,10 @@ __global__ __launch_bounds__(BLOCK) void utf8_filter_kernel(const Utf8Params p) 
   __shared__ u64 s_wave_bytes[NW];
   __shared__ u64 s_base_bytes;
   __shared__ int64_t s_tile;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int64_t ntiles = (p.nrows + TILE - 1) / TILE;
   while (true) {
+    const int lane = fresh_lane(), tid = wv * 64 + lane;   // (per tile: nothing derived from it is held across tiles)
     if (tid == 0) s_tile = (int64_t)atomicAdd(p.ticket, 1u);
     __syncthreads();
     const int64_t tile = uniform64(s_tile);
@@ -1996,6 +2026,13 @@ __global__ __launch_bounds__(BLOCK) void utf8_copy_kernel(const Utf8Params p) {
 #define CHQ_TU 0
 #endif
 hipError_t launch_filter_utf8(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
+
+#if CHQ_TU == 9   // development: ONE instantiation, for register-pressure experiments (scripts/kernel_resources.sh, -DCHQ_EXP_*)
+#ifndef CHQ_EXP_ARGS
+#define CHQ_EXP_ARGS 1024, 16, false, 0, true, 1, false, 0
+#endif
+template __global__ void filter_fused_kernel<CHQ_EXP_ARGS>(const FilterParams p);
+#endif
 
 #if CHQ_TU == 0 || CHQ_TU == 1
 hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int grid, hipStream_t stream) {
