@@ -283,6 +283,30 @@ def extra_lines(chq, torch, dev, ctx, n):
     except Exception as err:  # noqa: BLE001
         out["parquet_pipeline"] = {"error": repr(err)}
     ctx.set_option("trim_pool", 1); torch.cuda.empty_cache()
+    try:   # ---- BASELINE config 5: ONE rank's 1.25 B-row shard of the 10 B-row huge_simple.sql table (what --config 5 runs per GPU) ----
+        rows, batch_rows = 1_250_000_000, 125_000_000
+        batches, keep = build_config5_shard(chq, torch, dev, ctx, rows, batch_rows)
+        grp = chq.RecordGroup(batches, ctx)
+        pred = parse_expr(C5_PREDICATE)
+        outs = chq.filter_records(grp, [[], [], []], pred, ctx=ctx)
+        check_config5_outputs(torch, keep, outs, 0); check_config5_outputs(torch, keep, outs, len(outs) - 1)
+        for o in outs:
+            o.release()
+        run_config5_steps(chq, ctx, grp, pred, 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rows_out, kernel_ns, alg = run_config5_steps(chq, ctx, grp, pred, 3)
+        torch.cuda.synchronize(); secs = (time.perf_counter() - t0) / 3
+        kms = kernel_ns / 3 / 1e6
+        out["config5_shard"] = {
+            "workload": f"one GPU's shard of config 5: WHERE {C5_PREDICATE} over {rows} rows of id:Int32, value1:Utf8(8), value2:Float32 in "
+                        f"{len(batches)} device batches (10 GB of string bytes), ONE chq_filter_records call, one output per input batch",
+            "rows": rows, "rows_out": rows_out, "call_ms": secs * 1e3, "rows_per_s": rows / secs, "kernel_ms": kms, "algorithmic_bytes": alg,
+            "achieved_GBps": alg / (kms * 1e-3) / 1e9, "frac": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        grp.release()
+        del batches, keep
+    except Exception as err:  # noqa: BLE001
+        out["config5_shard"] = {"error": repr(err)}
+    ctx.set_option("trim_pool", 1); torch.cuda.empty_cache()
     return out
 
 

@@ -73,6 +73,10 @@ class ParquetImage(C.Structure):
     _fields_ = [("data", C.c_void_p), ("len", C.c_int64), ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 
+# chq_read_range_fn: int (*)(void* user, int64_t offset, int64_t length, uint8_t* dst)
+READ_RANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
+
+
 class CallStats(C.Structure):
     _fields_ = [("rows_in", C.c_int64), ("rows_out", C.c_int64), ("tiles", C.c_int64), ("launches", C.c_int64),
                 ("bytes_read_alg", C.c_int64), ("bytes_written_alg", C.c_int64), ("kernel_ns", C.c_int64)]
@@ -86,7 +90,8 @@ EXPORTED_SYMBOLS = [
     "chq_expr_nested", "chq_expr_unsupported", "chq_expr_free", "chq_filter_record", "chq_filter_records", "chq_filter_records_coalesced", "chq_plan_describe", "chq_project_record",
     "chq_compute_value", "chq_filter_project_record", "chq_record_to_device", "chq_record_to_host", "chq_wrap_columns",
     "chq_record_copy_to_peer", "chq_record_to_ipc", "chq_record_from_ipc", "chq_ipc_describe",
-    "chq_parquet_open", "chq_parquet_close", "chq_parquet_num_row_groups", "chq_parquet_row_group_num_rows",
+    "chq_parquet_open", "chq_parquet_open_reader", "chq_parquet_num_columns", "chq_parquet_column_name", "chq_parquet_read_columns",
+    "chq_parquet_close", "chq_parquet_num_row_groups", "chq_parquet_row_group_num_rows",
     "chq_parquet_describe", "chq_parquet_read_row_group", "chq_parquet_read_row_groups", "chq_record_to_parquet",
 ]
 
@@ -161,6 +166,10 @@ def lib():
         "chq_record_from_ipc": (ci, [vp, vp, i64, vp, i64, ci, ci, PDA, PS]),
         "chq_ipc_describe": (ci, [vp, i64, C.c_char_p, C.c_size_t]),
         "chq_parquet_open": (ci, [vp, i64, C.POINTER(vp), C.c_char_p, C.c_size_t]),
+        "chq_parquet_open_reader": (ci, [i64, READ_RANGE_FN, vp, C.POINTER(vp), C.c_char_p, C.c_size_t]),
+        "chq_parquet_num_columns": (C.c_int32, [vp]),
+        "chq_parquet_column_name": (C.c_char_p, [vp, C.c_int32]),
+        "chq_parquet_read_columns": (ci, [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, ci, vp, vp]),
         "chq_parquet_close": (None, [vp]),
         "chq_parquet_num_row_groups": (C.c_int32, [vp]),
         "chq_parquet_row_group_num_rows": (i64, [vp, C.c_int32]),

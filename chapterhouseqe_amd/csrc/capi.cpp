@@ -468,7 +468,29 @@ chq_status chq_parquet_open(const uint8_t* file, int64_t file_len, chq_parquet**
   if (err && err_len) { const size_t k = std::min(err_len - 1, text.size()); memcpy(err, text.data(), k); err[k] = 0; }
   return st;
 }
+chq_status chq_parquet_open_reader(int64_t file_len, chq_read_range_fn read, void* user, chq_parquet** out, char* err, size_t err_len) {
+  if (!out) return CHQ_ERR_ARROW_INVALID_ARGUMENT;
+  *out = nullptr;
+  std::string text;
+  chq_status st = CHQ_OK;
+  try {
+    if (!read) throw ChqError{CHQ_ERR_INVALID_HANDLE, "null range reader"};
+    auto* h = new chq_parquet();
+    try { h->file = parquet_open_reader(file_len, read, user); } catch (...) { delete h; throw; }
+    *out = h;
+  } catch (const ChqError& e) {
+    text = e.msg; st = (chq_status)e.code;
+  } catch (const std::exception& e) {
+    text = e.what(); st = CHQ_ERR_ARROW_INVALID_ARGUMENT;
+  }
+  if (err && err_len) { const size_t k = std::min(err_len - 1, text.size()); memcpy(err, text.data(), k); err[k] = 0; }
+  return st;
+}
 void chq_parquet_close(chq_parquet* pq) { delete pq; }
+int32_t chq_parquet_num_columns(const chq_parquet* pq) { return pq ? (int32_t)pq->file.columns.size() : 0; }
+const char* chq_parquet_column_name(const chq_parquet* pq, int32_t column) {
+  return pq && column >= 0 && column < (int32_t)pq->file.columns.size() ? pq->file.columns[(size_t)column].name.c_str() : nullptr;
+}
 int32_t chq_parquet_num_row_groups(const chq_parquet* pq) { return pq ? (int32_t)pq->file.row_groups.size() : 0; }
 int64_t chq_parquet_row_group_num_rows(const chq_parquet* pq, int32_t row_group) {
   return pq && row_group >= 0 && row_group < (int32_t)pq->file.row_groups.size() ? pq->file.row_groups[row_group].num_rows : -1;
@@ -496,6 +518,11 @@ chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32
 
 chq_status chq_parquet_read_row_groups(chq_ctx* ctx, const chq_parquet* pq, int32_t first, int32_t count, int out_device,
                                        ArrowDeviceArray* outs, ArrowSchema* out_schemas) {
+  return chq_parquet_read_columns(ctx, pq, first, count, nullptr, -1, out_device, outs, out_schemas);
+}
+
+chq_status chq_parquet_read_columns(chq_ctx* ctx, const chq_parquet* pq, int32_t first, int32_t count, const int32_t* columns,
+                                    int32_t n_columns, int out_device, ArrowDeviceArray* outs, ArrowSchema* out_schemas) {
   if (!ctx || !pq) return CHQ_ERR_INVALID_HANDLE;
   if (outs && out_schemas) for (int32_t i = 0; i < count; ++i) mark_released(&outs[i], &out_schemas[i]);
   return guarded(ctx, [&] {
@@ -503,7 +530,9 @@ chq_status chq_parquet_read_row_groups(chq_ctx* ctx, const chq_parquet* pq, int3
     if (out_device != ARROW_DEVICE_ROCM && out_device != ARROW_DEVICE_CPU)
       throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "out_device must be ARROW_DEVICE_CPU or ARROW_DEVICE_ROCM"};
     check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
-    std::vector<Batch> res = parquet_read_row_groups(ctx->c, pq->file, first, count);
+    if (!columns) n_columns = -1;
+    std::vector<Batch> res = parquet_read_row_groups(ctx->c, pq->file, first, count, columns, n_columns);
+    const chq_call_stats scan_stats = ctx->c.stats;
     try {
       for (size_t i = 0; i < res.size(); ++i) {
         if (out_device == ARROW_DEVICE_CPU) res[i] = to_host(ctx->c, res[i]);
@@ -516,6 +545,7 @@ chq_status chq_parquet_read_row_groups(chq_ctx* ctx, const chq_parquet* pq, int3
       }
       throw;
     }
+    ctx->c.stats = scan_stats;   // (to_host does not touch them today; the scan's counters are what the call reports)
   });
 }
 

@@ -8,8 +8,12 @@
 //
 // Scope: flat schemas (no repetition), optional or required columns (definition level <= 1), physical types BOOLEAN,
 // INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY (as Utf8); encodings PLAIN and RLE_DICTIONARY / PLAIN_DICTIONARY; data pages
-// V1 and V2; codec UNCOMPRESSED (what the reference's own writers produce: AsyncArrowWriter::try_new(.., None),
-// create_sample_data.rs:222, materialize_files_task.rs:128-133).  Anything else: CHQ_ERR_NOT_SUPPORTED with the reason.
+// V1 and V2; codecs UNCOMPRESSED (what the reference's own writers produce: AsyncArrowWriter::try_new(.., None),
+// create_sample_data.rs:222, materialize_files_task.rs:128-133) and SNAPPY (what the writers users have produce by default),
+// inflated on the GPU (parquet_codec.hip).  Anything else: CHQ_ERR_NOT_SUPPORTED with the reason.
+// Input: the whole file in host memory, or a range reader (the caller's storage reader fetches the footer and exactly the
+// column chunks a call decodes: read_files_task.rs:233-250 reads through opendal ranges the same way); a call decodes the
+// columns it is asked for (DEV_NOTES.md:123: column pruning).
 #pragma once
 #include <cstdint>
 #include <memory>
@@ -35,14 +39,15 @@ struct PqColumnSchema {
 
 struct PqPage {
   int type = 0;                 // PqPageType
-  int64_t header_at = 0;        // file offset of the page header
-  int64_t payload_at = 0;       // file offset of the first byte behind the header
+  int64_t header_at = 0;        // offset of the page header, relative to the first byte of its column chunk
+  int64_t payload_at = 0;       // offset of the first byte behind the header, relative to the chunk
   int64_t compressed_size = 0, uncompressed_size = 0;
   int64_t num_values = 0;       // rows of a data page (flat schema), entries of a dictionary page
   int encoding = 0;             // of the values
   int def_encoding = PQ_RLE;
   int64_t num_nulls = -1;       // V2 only
   int64_t def_bytes = 0, rep_bytes = 0;   // V2: byte lengths of the level sections (uncompressed, in front of the values)
+  bool v2_compressed = true;    // V2: is_compressed (the values section; the level sections never are)
 };
 
 struct PqColumnChunk {
@@ -53,6 +58,7 @@ struct PqColumnChunk {
   int64_t data_page_offset = 0, dictionary_page_offset = -1;
   int64_t stat_null_count = -1;   // from the chunk's Statistics, -1 = not recorded
   std::vector<int> encodings;
+  bool pages_parsed = false;    // a file opened over a range reader parses a chunk's page headers when the chunk is fetched
   std::vector<PqPage> pages;    // in file order, dictionary page (if any) first
   int64_t first_byte() const {   // (an empty chunk has a dictionary page and no data page: data_page_offset is 0 then)
     return dictionary_page_offset > 0 && (data_page_offset <= 0 || dictionary_page_offset < data_page_offset) ? dictionary_page_offset : data_page_offset;
@@ -64,8 +70,13 @@ struct PqRowGroup {
   std::vector<PqColumnChunk> columns;
 };
 
+// 0 = `length` bytes of the file starting at `offset` were written to `dst`; anything else fails the call
+typedef int (*PqReadRange)(void* user, int64_t offset, int64_t length, uint8_t* dst);
+
 struct PqFile {
-  const uint8_t* data = nullptr;   // borrowed: the whole file in host memory
+  const uint8_t* data = nullptr;   // borrowed: the whole file in host memory, or null for a file behind a range reader
+  PqReadRange read = nullptr;      // range reader (data == null)
+  void* read_user = nullptr;
   int64_t size = 0;
   int64_t num_rows = 0;
   std::string created_by;
@@ -76,6 +87,11 @@ struct PqFile {
 // Footer + every page header of every column chunk.  Throws ChqError (INVALID_ARGUMENT for a malformed file,
 // NOT_SUPPORTED for nested schemas).
 PqFile parquet_open(const uint8_t* data, int64_t size);
+// The same over a range reader: reads the tail of the file (footer), nothing else; page headers are parsed per chunk when a
+// call fetches the chunk.
+PqFile parquet_open_reader(int64_t size, PqReadRange read, void* user);
+// Page headers of one column chunk whose `csize` bytes start at `chunk`: fills c.pages (offsets relative to the chunk)
+void parquet_parse_pages(const uint8_t* chunk, int64_t csize, PqColumnChunk& c);
 // "rows R row_groups G created_by ..." / "column <name> <physical> <required|optional> [utf8]" /
 // "rg <i> rows <n>" / "chunk <col> values <n> codec <c> pages <p>" / "page <type> values <n> enc <e> bytes <b> header <h>" lines
 std::string parquet_describe(const PqFile& f);
@@ -85,8 +101,11 @@ struct Batch;
 struct Buffer;
 // One row group decoded into a device-resident batch (parquet_scan.cpp + parquet.hip).
 Batch parquet_read_row_group(Context& ctx, const PqFile& f, int row_group);
-// Several consecutive row groups, one batch each: their decodes overlap, the host synchronises twice per call
-std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int first, int count);
+// Several consecutive row groups, one batch each: their decodes overlap, the host synchronises twice per call.
+// `columns` (n_columns >= 0 entries, or null = every column): the columns to decode, in the order they are wanted -- only
+// their chunks are fetched, uploaded and decoded.
+std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int first, int count, const int32_t* columns = nullptr,
+                                           int n_columns = -1);
 
 // One record batch -> one complete Parquet file (one row group) in host memory (parquet_write.cpp + parquet_write.hip).
 struct ParquetImage {

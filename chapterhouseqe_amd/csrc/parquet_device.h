@@ -5,7 +5,7 @@
 
 namespace chq {
 
-enum : uint32_t { PQ_ERR_LEVELS = 1, PQ_ERR_VALUES = 2 };   // *err after a decode: which part of some page was malformed
+enum : uint32_t { PQ_ERR_LEVELS = 1, PQ_ERR_VALUES = 2, PQ_ERR_CODEC = 3 };   // *err after a decode: which part of some page was malformed
 
 // One data page of a column chunk.  Offsets are relative to the chunk buffer (the chunk as it lies in the file).
 struct PqPageDesc {
@@ -38,6 +38,31 @@ struct PqDecodeParams {
   uint32_t* dict_len_out;
   uint32_t* err;
 };
+
+// ---- page decompression (parquet_codec.hip) ---------------------------------------------------------------------------
+// A compressed chunk is inflated page by page into an uncompressed image of the chunk; the page descriptors point into that
+// image.  One job = one byte range of the raw chunk -> its place in the image.
+enum : uint32_t { PQ_CODEC_STORED = 0, PQ_CODEC_SNAPPY = 1 };
+enum : uint32_t { PQ_JOB_KEEP_LEVELS = 1 };   // with `page`: the column's definition levels are decoded (else only skipped)
+struct PqCodecJob {
+  uint32_t src_at, src_len;   // in the raw chunk buffer (the chunk as it lies in the file)
+  uint32_t dst_at, dst_len;   // in the image; dst_at is a multiple of 16, dst_len is what the page header promises
+  uint32_t codec;             // PQ_CODEC_*
+  int32_t page;               // >= 0: a V1 data page of an optional column -- [4-byte length][levels][values] can only be told
+                              // apart after inflation: the kernel fills levels_at / levels_len / values_at / values_len of pages[page]
+  uint32_t flags;             // PQ_JOB_*
+  uint32_t pad;
+};
+struct PqCodecParams {
+  const uint8_t* raw;
+  uint8_t* image;
+  const PqCodecJob* jobs;
+  int32_t n_jobs;
+  int32_t pad;
+  PqPageDesc* pages;
+  uint32_t* err;
+};
+hipError_t pq_launch_inflate(const PqCodecParams& p, hipStream_t s);
 
 struct PqRowParams {
   int64_t n_rows;

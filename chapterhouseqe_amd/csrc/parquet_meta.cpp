@@ -4,6 +4,7 @@
 // checks this half on the CPU tier against pyarrow's own metadata.
 #include "parquet.hpp"
 
+#include <algorithm>
 #include <cstring>
 
 #include "engine.hpp"
@@ -131,8 +132,9 @@ PqColumnChunk read_column_chunk(Thrift& t) {
   return c;
 }
 
+// `file` .. `file + size`: the bytes of ONE column chunk; `at`: offset of the page header inside it
 PqPage read_page_header(const uint8_t* file, int64_t size, int64_t at) {
-  if (at < 0 || at >= size) bad("page offset outside the file");
+  if (at < 0 || at >= size) bad("page offset outside its column chunk");
   Thrift t{file + at, file + size};
   PqPage pg;
   pg.header_at = at;
@@ -169,6 +171,7 @@ PqPage read_page_header(const uint8_t* file, int64_t size, int64_t at) {
             case 4: pg.encoding = (int)t.zigzag(); break;
             case 5: pg.def_bytes = t.zigzag(); break;
             case 6: pg.rep_bytes = t.zigzag(); break;
+            case 7: pg.v2_compressed = hty == Thrift::T_TRUE; break;
             default: t.skip(hty);
           }
         }
@@ -179,7 +182,7 @@ PqPage read_page_header(const uint8_t* file, int64_t size, int64_t at) {
   if (!typed) bad("page header without a type");
   pg.payload_at = (int64_t)(t.p - file);
   // sizes come from an untrusted file: compare by subtraction (a sum with a size near INT64_MAX wraps and passes)
-  if (pg.compressed_size < 0 || pg.compressed_size > size - pg.payload_at) bad("page payload runs past the file");
+  if (pg.compressed_size < 0 || pg.compressed_size > size - pg.payload_at) bad("page payload runs past its column chunk");
   if (pg.uncompressed_size < 0 || pg.uncompressed_size >= (1ll << 31)) bad("page of " + std::to_string(pg.uncompressed_size) + " bytes");
   if (pg.num_values < 0 || pg.num_values >= (1ll << 31)) bad("page with " + std::to_string(pg.num_values) + " values");
   if (pg.def_bytes < 0 || pg.rep_bytes < 0) bad("negative level section length");
@@ -193,17 +196,10 @@ const char* type_name(int t) {
 
 }  // namespace
 
-PqFile parquet_open(const uint8_t* data, int64_t size) {
-  if (!data || size < 12) bad("file shorter than the magic numbers");
-  if (memcmp(data, "PAR1", 4) != 0 || memcmp(data + size - 4, "PAR1", 4) != 0) {
-    if (memcmp(data + size - 4, "PARE", 4) == 0) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: encrypted footer"};
-    bad("magic number PAR1 missing");
-  }
-  uint32_t flen; memcpy(&flen, data + size - 8, 4);
-  if ((int64_t)flen + 12 > size) bad("footer length larger than the file");
-  Thrift t{data + size - 8 - flen, data + size - 8};
-  PqFile f;
-  f.data = data; f.size = size;
+namespace {
+// FileMetaData (the footer) -> schema, row groups, column chunk metadata; no page headers
+void read_footer(const uint8_t* meta, int64_t meta_len, int64_t file_size, PqFile& f) {
+  Thrift t{meta, meta + meta_len};
   std::vector<RawSchemaElement> schema;
   int id, ty, last = 0;
   while (t.field(id, ty, last)) {
@@ -235,26 +231,77 @@ PqFile parquet_open(const uint8_t* data, int64_t size) {
     f.columns.push_back(schema[i].col);
   }
   for (PqRowGroup& rg : f.row_groups) {
+    if (rg.num_rows < 0) bad("row group with a negative row count");
     if (rg.columns.size() != f.columns.size()) bad("row group with " + std::to_string(rg.columns.size()) + " column chunks for " + std::to_string(f.columns.size()) + " columns");
     for (PqColumnChunk& c : rg.columns) {
-      if (c.num_values == 0) continue;   // an empty chunk: writers leave its offsets at 0
-      int64_t at = c.first_byte();
       if (c.num_values < 0) bad("column chunk with a negative value count");
-      if (at < 4 || c.total_compressed_size < 0 || c.total_compressed_size > size - 8 - at) bad("column chunk outside the file");
-      const int64_t chunk_end = at + c.total_compressed_size;
-      int64_t values = 0;
-      while (at < chunk_end && values < c.num_values) {
-        PqPage pg = read_page_header(data, chunk_end, at);   // (a page may not run past its chunk either)
-        at = pg.payload_at + pg.compressed_size;
-        if (pg.type == PQ_DATA_PAGE || pg.type == PQ_DATA_PAGE_V2) {
-          if (pg.num_values > c.num_values - values) bad("page with more values than its chunk has left");
-          values += pg.num_values;
-        }
-        c.pages.push_back(pg);
-      }
-      if (values != c.num_values) bad("pages hold " + std::to_string(values) + " values, the chunk's metadata says " + std::to_string(c.num_values));
+      if (c.num_values == 0) continue;   // an empty chunk: writers leave its offsets at 0
+      // sizes come from an untrusted file: compare by subtraction (a sum with a size near INT64_MAX wraps and passes)
+      const int64_t at = c.first_byte();
+      if (at < 4 || c.total_compressed_size < 0 || c.total_compressed_size > file_size - 8 - at) bad("column chunk outside the file");
     }
   }
+}
+}  // namespace
+
+void parquet_parse_pages(const uint8_t* chunk, int64_t csize, PqColumnChunk& c) {
+  c.pages.clear();
+  int64_t at = 0, values = 0;
+  while (at < csize && values < c.num_values) {
+    PqPage pg = read_page_header(chunk, csize, at);   // (a page may not run past its chunk)
+    at = pg.payload_at + pg.compressed_size;
+    if (pg.type == PQ_DATA_PAGE || pg.type == PQ_DATA_PAGE_V2) {
+      if (pg.num_values > c.num_values - values) bad("page with more values than its chunk has left");
+      values += pg.num_values;
+    }
+    c.pages.push_back(pg);
+  }
+  if (values != c.num_values) bad("pages hold " + std::to_string(values) + " values, the chunk's metadata says " + std::to_string(c.num_values));
+  c.pages_parsed = true;
+}
+
+PqFile parquet_open(const uint8_t* data, int64_t size) {
+  if (!data || size < 12) bad("file shorter than the magic numbers");
+  if (memcmp(data, "PAR1", 4) != 0 || memcmp(data + size - 4, "PAR1", 4) != 0) {
+    if (memcmp(data + size - 4, "PARE", 4) == 0) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: encrypted footer"};
+    bad("magic number PAR1 missing");
+  }
+  uint32_t flen; memcpy(&flen, data + size - 8, 4);
+  if ((int64_t)flen + 12 > size) bad("footer length larger than the file");
+  PqFile f;
+  f.data = data; f.size = size;
+  read_footer(data + size - 8 - flen, (int64_t)flen, size, f);
+  for (PqRowGroup& rg : f.row_groups)
+    for (PqColumnChunk& c : rg.columns)
+      if (c.num_values > 0) parquet_parse_pages(data + c.first_byte(), c.total_compressed_size, c);
+      else c.pages_parsed = true;
+  return f;
+}
+
+PqFile parquet_open_reader(int64_t size, PqReadRange read, void* user) {
+  if (!read || size < 12) bad("file shorter than the magic numbers");
+  // one read for the tail: the footer is almost always inside the last 64 KiB; a longer one costs a second read
+  std::vector<uint8_t> tail((size_t)std::min<int64_t>(size, 64 << 10));
+  if (read(user, size - (int64_t)tail.size(), (int64_t)tail.size(), tail.data()) != 0) bad("the range reader failed on the file tail");
+  const uint8_t* e = tail.data() + tail.size();
+  if (memcmp(e - 4, "PAR1", 4) != 0) {
+    if (memcmp(e - 4, "PARE", 4) == 0) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: encrypted footer"};
+    bad("magic number PAR1 missing");
+  }
+  uint32_t flen; memcpy(&flen, e - 8, 4);
+  if ((int64_t)flen + 12 > size) bad("footer length larger than the file");
+  std::vector<uint8_t> meta;
+  const uint8_t* mp;
+  if ((size_t)flen + 8 <= tail.size()) mp = e - 8 - flen;
+  else {
+    meta.resize(flen);
+    if (read(user, size - 8 - (int64_t)flen, (int64_t)flen, meta.data()) != 0) bad("the range reader failed on the footer");
+    mp = meta.data();
+  }
+  PqFile f;
+  f.read = read; f.read_user = user; f.size = size;
+  read_footer(mp, (int64_t)flen, size, f);
+  for (PqRowGroup& rg : f.row_groups) for (PqColumnChunk& c : rg.columns) if (c.num_values == 0) c.pages_parsed = true;
   return f;
 }
 

@@ -1,4 +1,5 @@
 // parquet_scan.cpp -- orchestration of the GPU page decode (parquet.hip) for one row group.  See parquet.hpp for scope.
+#include <algorithm>
 #include <cstring>
 
 #include "engine.hpp"
@@ -10,13 +11,6 @@ namespace {
 
 [[noreturn]] void unsupported(const std::string& what) { throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: " + what}; }
 [[noreturn]] void malformed(const std::string& what) { throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: " + what}; }
-
-template <typename T>
-BufferPtr upload(Context& ctx, hipStream_t stream, const std::vector<T>& v) {
-  auto b = make_device_buffer(v.size() * sizeof(T) + 16, ctx.device);
-  if (!v.empty()) check_hip(hipMemcpyAsync(b->ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream), "upload page table");
-  return b;
-}
 
 // the columns' streams: forked off ctx.stream and joined back into it with events (engine.cpp: fork_aux_streams /
 // join_aux_streams).  Round 2 synchronised on the host instead, after a segfault whose cause is now known: the context ran
@@ -46,11 +40,28 @@ struct ColumnWork {
   bool byte_array = false, boolean = false;
   bool has_levels = false;    // definition levels are decoded (optional column whose statistics do not rule nulls out)
   int64_t rows = 0;
-  BufferPtr chunkb, pages, nonnull, value_base, valid8, row_val, dense, vsrc, vlen, dict_src, dict_len, offsets, block_sums;
+  BufferPtr chunkb, pages_dev, nonnull, value_base, valid8, row_val, dense, vsrc, vlen, dict_src, dict_len, offsets, block_sums;
+  BufferPtr rawb;                // a compressed chunk as it lies in the file (chunkb is then its uncompressed image)
   std::vector<BufferPtr> keep;   // page lists: alive until the stream has run
-  std::vector<std::vector<uint32_t>> host_keep;
+  // Sources of the asynchronous uploads (page tables, page lists, dictionary positions, a chunk fetched through the range
+  // reader): pageable host memory the copy engine may read after the call that queued the copy has returned, so they live
+  // as long as the column's work item -- until the host has synchronised with the column's stream.
+  std::vector<std::shared_ptr<void>> host_keep;
+  std::vector<PqPage> pages;     // the chunk's page headers (parsed here for a file behind a range reader)
   int64_t host_values = 0;    // non-null values when known on the host (no levels)
+  int64_t uploaded = 0;       // file bytes sent to the GPU for this column
 };
+
+template <typename T>
+BufferPtr upload(Context& ctx, hipStream_t stream, const std::vector<T>& v, ColumnWork& w) {
+  auto b = make_device_buffer(v.size() * sizeof(T) + 16, ctx.device);
+  if (!v.empty()) {
+    auto keep = std::make_shared<std::vector<T>>(v);
+    check_hip(hipMemcpyAsync(b->ptr, keep->data(), keep->size() * sizeof(T), hipMemcpyHostToDevice, stream), "upload page table");
+    w.host_keep.push_back(keep);
+  }
+  return b;
+}
 
 }  // namespace
 
@@ -63,12 +74,12 @@ struct RowGroupJob {   // one row group between its two phases
 };
 
 // ---- phase A: everything up to the Utf8 offsets, the columns side by side on the auxiliary streams (already forked) -----
-void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, size_t stream_shift) {
+void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, size_t stream_shift, const std::vector<int>& sel) {
   if (row_group < 0 || row_group >= (int)f.row_groups.size()) malformed("row group " + std::to_string(row_group) + " of " + std::to_string(f.row_groups.size()));
   const PqRowGroup& rg = f.row_groups[row_group];
   const int64_t rows = rg.num_rows;
   if (rows < 0 || rows >= (1ll << 31)) unsupported("row group of " + std::to_string(rows) + " rows");
-  const size_t nc = f.columns.size();
+  const size_t nc = sel.size();   // the columns this call decodes (work item ci <-> file column sel[ci])
   job.rows = rows;
   job.work.assign(nc, ColumnWork{});
   std::vector<ColumnWork>& work = job.work;
@@ -76,13 +87,18 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
   Scalars* dscal = (Scalars*)job.scal->ptr;   // (allocated and zeroed by the caller, on ctx.stream, before the streams forked)
   for (size_t ci = 0; ci < nc; ++ci) {
     const hipStream_t cstream = ctx.aux[(ci + stream_shift) % Context::kAuxStreams];
-    const PqColumnSchema& cs = f.columns[ci];
-    const PqColumnChunk& cc = rg.columns[ci];
+    const PqColumnSchema& cs = f.columns[(size_t)sel[ci]];
+    const PqColumnChunk& cc = rg.columns[(size_t)sel[ci]];
     ColumnWork& w = work[ci];
     w.schema = &cs; w.chunk = &cc; w.rows = rows;
     if (cs.repetition > 1) unsupported("repeated column '" + cs.name + "'");
     if (cs.logical_other) unsupported("logical type of column '" + cs.name + "'");
-    if (cc.codec != 0) unsupported("compression codec " + std::to_string(cc.codec) + " (column '" + cs.name + "'); only UNCOMPRESSED, which is what the reference's writers produce");
+    if (cc.codec != 0 && cc.codec != 1) {
+      static const char* kCodec[] = {"UNCOMPRESSED", "SNAPPY", "GZIP", "LZO", "BROTLI", "LZ4", "ZSTD", "LZ4_RAW"};
+      unsupported(std::string("compression codec ") + (cc.codec >= 0 && cc.codec < 8 ? kCodec[cc.codec] : std::to_string(cc.codec).c_str()) +
+                  " (column '" + cs.name + "'); UNCOMPRESSED and SNAPPY pages are decoded");
+    }
+    const bool compressed = cc.codec == 1;
     if (cc.num_values != rows) malformed("column '" + cs.name + "' holds " + std::to_string(cc.num_values) + " values for " + std::to_string(rows) + " rows");
     const bool is_string = cs.logical_string || cs.converted_type == 0;
     if (cs.converted_type > 0 && !((cs.converted_type == 17 && cs.type == PQ_INT32) || (cs.converted_type == 18 && cs.type == PQ_INT64)))
@@ -101,9 +117,30 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
     const int64_t first = rows ? cc.first_byte() : 0, csize = rows ? cc.total_compressed_size : 0;
     if (csize < 0 || first < 0 || csize > f.size - first) malformed("column chunk outside the file");
     if (csize >= (1ll << 32) - 64) unsupported("column chunk of " + std::to_string(csize) + " bytes");
-    w.chunkb = make_device_buffer((size_t)csize + 64, ctx.device);
-    check_hip(hipMemcpyAsync(w.chunkb->ptr, f.data + first, (size_t)csize, hipMemcpyHostToDevice, cstream), "upload column chunk");
-    check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + csize, 0, 64, cstream), "memset");
+    // the chunk's bytes: where they lie in the caller's memory, or fetched through the caller's range reader (exactly this
+    // chunk: columns a call does not ask for are never read)
+    const uint8_t* chunk_host = nullptr;
+    if (csize > 0) {
+      if (f.data) chunk_host = f.data + first;
+      else {
+        auto hb = make_host_buffer((size_t)csize + 16);
+        if (f.read(f.read_user, first, csize, (uint8_t*)hb->ptr) != 0) malformed("the range reader failed on column '" + cs.name + "' (" + std::to_string(csize) + " bytes at " + std::to_string(first) + ")");
+        chunk_host = (const uint8_t*)hb->ptr;
+        w.host_keep.push_back(hb);
+      }
+    }
+    const std::vector<PqPage>* chunk_pages = &cc.pages;
+    if (!cc.pages_parsed) {   // (file behind a range reader: the headers are parsed from the bytes just fetched)
+      PqColumnChunk tmp = cc;
+      if (csize > 0) parquet_parse_pages(chunk_host, csize, tmp);
+      w.pages = std::move(tmp.pages);
+      chunk_pages = &w.pages;
+    }
+    BufferPtr raw = make_device_buffer((size_t)csize + 64, ctx.device);
+    if (csize > 0) check_hip(hipMemcpyAsync(raw->ptr, chunk_host, (size_t)csize, hipMemcpyHostToDevice, cstream), "upload column chunk");
+    check_hip(hipMemsetAsync((uint8_t*)raw->ptr + csize, 0, 64, cstream), "memset");
+    w.uploaded = csize;
+    if (!compressed) w.chunkb = raw; else w.rawb = raw;   // (compressed: chunkb = the uncompressed image, allocated below)
 
     const bool optional = cs.repetition == 1;
     w.has_levels = optional && cc.stat_null_count != 0;
@@ -113,14 +150,54 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
     uint32_t dict_at = 0, dict_len = 0, dict_count = 0;
     bool have_dict = false;
     int64_t row_at = 0;
-    for (const PqPage& pg : cc.pages) {
-      if (pg.compressed_size != pg.uncompressed_size) malformed("uncompressed page whose sizes differ");
-      const int64_t rel = pg.payload_at - first;
-      if (rel < 0 || pg.compressed_size < 0 || pg.compressed_size > csize - rel) malformed("page outside its column chunk");
+    // Compressed chunk: every page is inflated into an uncompressed IMAGE of the chunk (pages back to back, 16-byte
+    // aligned) and `rel` / the descriptors below point into that image; uncompressed chunk: the image is the chunk itself.
+    std::vector<PqCodecJob> jobs;
+    int64_t image_at = 0;
+    for (const PqPage& pg : *chunk_pages) {
+      if (!compressed && pg.compressed_size != pg.uncompressed_size) malformed("uncompressed page whose sizes differ");
+      const int64_t raw_rel = pg.payload_at;   // (page offsets are relative to the chunk)
+      if (raw_rel < 0 || pg.compressed_size < 0 || pg.compressed_size > csize - raw_rel) malformed("page outside its column chunk");
+      if (pg.uncompressed_size < 0 || pg.uncompressed_size >= (1ll << 31)) malformed("page size");
+      int64_t rel = raw_rel;
+      int64_t v2_values_at = 0, v2_values_len = 0;   // compressed V2 page: where its values section lands in the image
+      if (compressed) {
+        if (pg.type == PQ_INDEX_PAGE) continue;
+        rel = image_at;
+        image_at += (pg.uncompressed_size + 15) / 16 * 16;
+        if (image_at >= (1ll << 32) - 64) unsupported("column chunk of more than 4 GiB uncompressed");
+        PqCodecJob j{};
+        j.src_at = (uint32_t)raw_rel; j.src_len = (uint32_t)pg.compressed_size; j.dst_at = (uint32_t)rel; j.dst_len = (uint32_t)pg.uncompressed_size;
+        j.codec = PQ_CODEC_SNAPPY; j.page = -1;
+        if (pg.type == PQ_DATA_PAGE_V2) {
+          // the level sections lie uncompressed in front of the values section, which is compressed unless the header says not
+          const int64_t lv = pg.def_bytes + pg.rep_bytes;
+          if (pg.def_bytes < 0 || pg.rep_bytes < 0 || lv > pg.compressed_size || lv > pg.uncompressed_size) malformed("level sections run past the page");
+          if (lv > 0) {
+            PqCodecJob l = j;
+            l.src_len = (uint32_t)lv; l.dst_len = (uint32_t)lv; l.codec = PQ_CODEC_STORED;
+            jobs.push_back(l);
+          }
+          // (the values section starts at an arbitrary byte of the image: the inflate kernel wants 16-byte aligned
+          // destinations, so the values get their own aligned slot and the levels stay where they are)
+          const int64_t vrel = image_at;
+          image_at += (pg.uncompressed_size - lv + 15) / 16 * 16;
+          j.src_at = (uint32_t)(raw_rel + lv); j.src_len = (uint32_t)(pg.compressed_size - lv);
+          j.dst_at = (uint32_t)vrel; j.dst_len = (uint32_t)(pg.uncompressed_size - lv);
+          if (!pg.v2_compressed) j.codec = PQ_CODEC_STORED;
+          if (j.dst_len > 0 || j.src_len > 0) jobs.push_back(j);
+          v2_values_at = vrel; v2_values_len = pg.uncompressed_size - lv;
+        } else {
+          if (pg.type == PQ_DATA_PAGE && cs.repetition == 1) {   // [4-byte length][levels][values]: told apart on the device
+            j.page = -2;   // patched to the descriptor's index below
+          }
+          jobs.push_back(j);
+        }
+      }
       if (pg.type == PQ_DICTIONARY_PAGE) {
         if (pg.encoding != PQ_PLAIN && pg.encoding != PQ_PLAIN_DICTIONARY) unsupported("dictionary page encoding " + std::to_string(pg.encoding));
         if (pg.num_values < 0 || pg.num_values >= (1ll << 31)) malformed("dictionary size");
-        dict_at = (uint32_t)rel; dict_len = (uint32_t)pg.compressed_size; dict_count = (uint32_t)pg.num_values; have_dict = true;
+        dict_at = (uint32_t)rel; dict_len = (uint32_t)pg.uncompressed_size; dict_count = (uint32_t)pg.num_values; have_dict = true;
         continue;
       }
       if (pg.type == PQ_INDEX_PAGE) continue;
@@ -128,21 +205,30 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       PqPageDesc d{};
       if (pg.num_values < 0 || pg.num_values > rows - row_at) malformed("page of column '" + cs.name + "' holds more rows than the row group has left");
       d.num_rows = (uint32_t)pg.num_values; d.first_row = row_at;
-      int64_t at = rel, left = pg.compressed_size;
+      int64_t at = rel, left = pg.uncompressed_size;
       if (pg.type == PQ_DATA_PAGE) {
         if (optional) {   // [4-byte length][RLE hybrid levels]
           if (pg.def_encoding != PQ_RLE) unsupported("definition level encoding " + std::to_string(pg.def_encoding));
           if (left < 4) malformed("page too short for its definition levels");
-          uint32_t l; memcpy(&l, f.data + pg.payload_at, 4);
-          if ((int64_t)l + 4 > left) malformed("definition levels run past the page");
-          d.levels_at = (uint32_t)(at + 4); d.levels_len = l;
-          at += 4 + l; left -= 4 + l;
+          if (compressed) {
+            // the length prefix is inside the compressed payload: the inflate kernel reads it and fills in the descriptor
+            // (levels_at / levels_len / values_at / values_len) before the decode kernels, queued behind it, read it
+            for (size_t k = jobs.size(); k-- > 0;) if (jobs[k].page == -2) { jobs[k].page = (int32_t)descs.size(); jobs[k].flags = w.has_levels ? PQ_JOB_KEEP_LEVELS : 0; break; }
+            d.levels_at = (uint32_t)at; d.levels_len = w.has_levels ? 1 : 0;   // (placeholder: "has levels", see the check below)
+            at = rel; left = 0;
+          } else {
+            uint32_t l; memcpy(&l, chunk_host + raw_rel, 4);
+            if ((int64_t)l + 4 > left) malformed("definition levels run past the page");
+            d.levels_at = (uint32_t)(at + 4); d.levels_len = l;
+            at += 4 + l; left -= 4 + l;
+          }
         }
       } else {
         if (pg.rep_bytes != 0) unsupported("repetition levels");
         if (pg.def_bytes < 0 || pg.def_bytes > left) malformed("definition levels run past the page");
         d.levels_at = (uint32_t)at; d.levels_len = (uint32_t)pg.def_bytes;
-        at += pg.def_bytes; left -= pg.def_bytes;
+        if (compressed) { at = v2_values_at; left = v2_values_len; }
+        else { at += pg.def_bytes; left -= pg.def_bytes; }
         if (!optional && pg.def_bytes != 0) malformed("definition levels on a required column");
       }
       if (optional && w.has_levels && d.levels_len == 0 && d.num_rows > 0) malformed("optional column without definition levels");
@@ -161,13 +247,23 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
     }
     if (row_at != rows) malformed("pages of column '" + cs.name + "' hold " + std::to_string(row_at) + " rows, the row group has " + std::to_string(rows));
     const int n_pages = (int)descs.size();
-    w.pages = upload(ctx, cstream, descs);
-    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_nonnull);
-    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_base);
+    w.pages_dev = upload(ctx, cstream, descs, w);
+    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_nonnull, w);
+    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_base, w);
     w.host_values = rows;
+    if (compressed) {   // inflate every page into the image; the decode kernels below are queued behind it on the same stream
+      w.chunkb = make_device_buffer((size_t)image_at + 64, ctx.device);
+      check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + image_at, 0, 64, cstream), "memset");
+      auto jobs_dev = upload(ctx, cstream, jobs, w);
+      w.keep.push_back(jobs_dev);
+      PqCodecParams cp{};
+      cp.raw = (const uint8_t*)w.rawb->ptr; cp.image = (uint8_t*)w.chunkb->ptr; cp.jobs = (const PqCodecJob*)jobs_dev->ptr;
+      cp.n_jobs = (int32_t)jobs.size(); cp.pages = (PqPageDesc*)w.pages_dev->ptr; cp.err = &dscal[ci].err;
+      check_hip(pq_launch_inflate(cp, cstream), "launch pq_inflate_kernel");
+    }
 
     PqDecodeParams p{};
-    p.chunk = (const uint8_t*)w.chunkb->ptr; p.pages = (const PqPageDesc*)w.pages->ptr; p.n_pages = n_pages; p.width = w.width;
+    p.chunk = (const uint8_t*)w.chunkb->ptr; p.pages = (const PqPageDesc*)w.pages_dev->ptr; p.n_pages = n_pages; p.width = w.width;
     p.nonnull = (uint32_t*)w.nonnull->ptr; p.value_base = (uint32_t*)w.value_base->ptr;
     p.total_values = &dscal[ci].total_values; p.err = &dscal[ci].err;
     p.dict_at = dict_at; p.dict_len = dict_len; p.dict_count = dict_count;
@@ -181,7 +277,7 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       check_hip(pq_launch_rowval(p, cstream), "launch pq_rowval_kernel");
     }
     // dense values: at most `rows` of them
-    auto plain_dev = upload(ctx, cstream, plain_list), dict_dev = upload(ctx, cstream, dict_list), rle_dev = upload(ctx, cstream, rle_list);
+    auto plain_dev = upload(ctx, cstream, plain_list, w), dict_dev = upload(ctx, cstream, dict_list, w), rle_dev = upload(ctx, cstream, rle_list, w);
     w.keep.push_back(plain_dev); w.keep.push_back(dict_dev); w.keep.push_back(rle_dev);
     if (w.byte_array) {
       w.vsrc = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
@@ -190,9 +286,9 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       if (!dict_list.empty()) {
         // The dictionary page is ONE page: on the GPU a single workgroup would walk its length prefixes (5 ms for 1 MB of
         // ragged strings).  The host has the bytes and walks them in ~0.2 ms while it prepares the launches.
-        std::vector<uint32_t> h_src(dict_count), h_len(dict_count);
-        {
-          const uint8_t* dp = f.data + first + dict_at;
+        if (!compressed) {
+          std::vector<uint32_t> h_src(dict_count), h_len(dict_count);
+          const uint8_t* dp = chunk_host + dict_at;
           uint64_t pos = 0;
           for (uint32_t i = 0; i < dict_count; ++i) {
             if (pos + 4 > dict_len) malformed("dictionary page of column '" + cs.name + "' ends inside an entry");
@@ -201,10 +297,15 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
             h_src[i] = dict_at + (uint32_t)pos + 4; h_len[i] = l;
             pos += 4 + (uint64_t)l;
           }
+          w.dict_src = upload(ctx, cstream, h_src, w);
+          w.dict_len = upload(ctx, cstream, h_len, w);
+        } else {   // the page is only readable after inflation: one workgroup walks it on the device
+          w.dict_src = make_device_buffer((size_t)dict_count * 4 + 16, ctx.device);
+          w.dict_len = make_device_buffer((size_t)dict_count * 4 + 16, ctx.device);
+          PqDecodeParams dpw = p;
+          dpw.walk_dictionary = 1; dpw.dict_src = (uint32_t*)w.dict_src->ptr; dpw.dict_len_out = (uint32_t*)w.dict_len->ptr;
+          if (dict_count > 0) check_hip(pq_launch_ba_walk(dpw, 1, cstream), "launch pq_ba_walk_kernel (dictionary)");
         }
-        w.dict_src = upload(ctx, cstream, h_src);
-        w.dict_len = upload(ctx, cstream, h_len);
-        w.host_keep.push_back(std::move(h_src)); w.host_keep.push_back(std::move(h_len));   // (pageable upload sources: alive until the stream ran)
         p.dict_src = (uint32_t*)w.dict_src->ptr; p.dict_len_out = (uint32_t*)w.dict_len->ptr;
         p.page_list = (const int32_t*)dict_dev->ptr;
         check_hip(pq_launch_dict_ba(p, (int)dict_list.size(), cstream), "launch pq_dict_ba_kernel");
@@ -256,7 +357,7 @@ Batch phase_b(Context& ctx, RowGroupJob& job, size_t stream_shift) {
   for (size_t ci = 0; ci < nc; ++ci) {
     const hipStream_t cstream = ctx.aux[(ci + stream_shift) % Context::kAuxStreams];
     ColumnWork& w = work[ci];
-    if (hs[ci].err) malformed(std::string(hs[ci].err == PQ_ERR_LEVELS ? "definition levels" : "values") + " of column '" + w.schema->name + "' are malformed");
+    if (hs[ci].err) malformed(std::string(hs[ci].err == PQ_ERR_CODEC ? "compressed pages" : hs[ci].err == PQ_ERR_LEVELS ? "definition levels" : "values") + " of column '" + w.schema->name + "' are malformed");
     Column o;
     o.name = w.schema->name; o.format = w.format; o.nullable = w.schema->repetition == 1; o.length = rows; o.offset = 0;
     parse_arrow_format(w.format, &o.type, &o.width);
@@ -311,10 +412,20 @@ Batch phase_b(Context& ctx, RowGroupJob& job, size_t stream_shift) {
 
 // Row groups [first, first + count): phase A of all of them is in flight before the first size is read back, so the two
 // host synchronisations are paid once per call (per wave of about 1 GiB of column chunks), not once per row group, and the
-// upload of one row group overlaps the decode of the previous ones.
-std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int first, int count) {
+// upload of one row group overlaps the decode of the previous ones.  Only the columns in `columns` are fetched and decoded.
+std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int first, int count, const int32_t* columns, int n_columns) {
   if (first < 0 || count < 0 || first + count > (int)f.row_groups.size())
     malformed("row groups [" + std::to_string(first) + ", " + std::to_string(first + count) + ") of " + std::to_string(f.row_groups.size()));
+  std::vector<int> sel;
+  if (!columns || n_columns < 0) { for (size_t i = 0; i < f.columns.size(); ++i) sel.push_back((int)i); }
+  else {
+    for (int k = 0; k < n_columns; ++k) {
+      if (columns[k] < 0 || columns[k] >= (int)f.columns.size())
+        throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: column index " + std::to_string(columns[k]) + " of " + std::to_string(f.columns.size())};
+      sel.push_back(columns[k]);
+    }
+  }
+  ctx.stats = chq_call_stats{};
   std::vector<Batch> outs;
   outs.reserve((size_t)count);
   int next = first;
@@ -323,28 +434,40 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
     int64_t wave_bytes = 0;
     while (wave_end < first + count) {   // a wave: about 1 GiB of column chunks resident at once (at least one row group)
       int64_t b = 0;
-      for (const PqColumnChunk& c : f.row_groups[(size_t)wave_end].columns) b += c.total_compressed_size;
+      for (int ci : sel) b += f.row_groups[(size_t)wave_end].columns[(size_t)ci].total_compressed_size;
       if (wave_end > next && wave_bytes + b > ((int64_t)1 << 30)) break;
       wave_bytes += b; ++wave_end;
     }
     std::vector<RowGroupJob> jobs((size_t)(wave_end - next));
     DrainOnUnwind drain{ctx};   // (declared after `jobs`: runs before their buffers are released)
     for (RowGroupJob& job : jobs) {
-      job.scal = make_device_buffer(sizeof(Scalars) * (f.columns.size() + 1), ctx.device);
-      check_hip(hipMemsetAsync(job.scal->ptr, 0, sizeof(Scalars) * (f.columns.size() + 1), ctx.stream), "memset");
+      job.scal = make_device_buffer(sizeof(Scalars) * (sel.size() + 1), ctx.device);
+      check_hip(hipMemsetAsync(job.scal->ptr, 0, sizeof(Scalars) * (sel.size() + 1), ctx.stream), "memset");
     }
     fork_streams(ctx);
-    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j * f.columns.size());
+    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j * sel.size(), sel);
     join_streams(ctx);
     for (RowGroupJob& job : jobs)
-      check_hip(hipMemcpyAsync(job.hs.data(), job.scal->ptr, sizeof(Scalars) * job.work.size(), hipMemcpyDeviceToHost, ctx.stream), "read back");
+      if (!job.work.empty()) check_hip(hipMemcpyAsync(job.hs.data(), job.scal->ptr, sizeof(Scalars) * job.work.size(), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
     fork_streams(ctx);
-    for (size_t j = 0; j < jobs.size(); ++j) outs.push_back(phase_b(ctx, jobs[j], j * f.columns.size()));
+    for (size_t j = 0; j < jobs.size(); ++j) {
+      outs.push_back(phase_b(ctx, jobs[j], j * sel.size()));
+      // (chq_call_stats of a scan: rows decoded, file bytes sent to the GPU, Arrow bytes produced)
+      ctx.stats.rows_in += jobs[j].rows; ctx.stats.rows_out += jobs[j].rows;
+      for (const ColumnWork& w : jobs[j].work) ctx.stats.bytes_read_alg += w.uploaded;
+    }
     join_streams(ctx);
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // the temporaries of `jobs` are released here
     next = wave_end;
   }
+  for (const Batch& b : outs)
+    for (const Column& c : b.cols) {
+      if (c.type == T_UTF8) ctx.stats.bytes_written_alg += (c.length + 1) * 4 + std::max<int64_t>(0, c.data_bytes);
+      else if (c.type == T_BOOL) ctx.stats.bytes_written_alg += (c.length + 7) / 8;
+      else ctx.stats.bytes_written_alg += c.length * c.width;
+      if (c.validity) ctx.stats.bytes_written_alg += (c.length + 7) / 8;
+    }
   return outs;
 }
 

@@ -481,17 +481,47 @@ class ParquetFile:
     of what `read_files_task.rs:233-282` does with `ParquetRecordBatchStreamBuilder`.  `source`: a path or the file's
     bytes; they stay referenced (the library borrows the memory) until `close()`."""
 
-    def __init__(self, source):
+    def __init__(self, source, *, reader=None, size: Optional[int] = None):
+        """`source`: a path or the file's bytes (the library borrows the memory).  Or `reader(offset, length) -> bytes` with
+        `size` = the file's length (`chq_parquet_open_reader`): the footer is read at open, and each read call then fetches
+        exactly the column chunks it decodes -- what the reference's opendal reader does (read_files_task.rs:233-250).
+        `self.reads` records every (offset, length) the library asked for."""
         import numpy as np
-        if isinstance(source, (bytes, bytearray, memoryview)):
-            self._bytes = np.frombuffer(source, dtype=np.uint8)
-        else:
-            self._bytes = np.fromfile(source, dtype=np.uint8)
         self._h = C.c_void_p()
+        self.reads: List[Tuple[int, int]] = []
         err = C.create_string_buffer(1024)
-        rc = L.lib().chq_parquet_open(self._bytes.ctypes.data, self._bytes.size, C.byref(self._h), err, len(err))
+        if reader is not None:
+            if size is None:
+                raise ValueError("a range reader needs the file's size")
+
+            def _read(_user, offset, length, dst):
+                try:
+                    data = reader(offset, length)
+                    if len(data) != length:
+                        return 1
+                    C.memmove(dst, bytes(data), length)
+                    self.reads.append((int(offset), int(length)))
+                    return 0
+                except Exception:   # noqa: BLE001 -- a failing reader fails the call with a status, not a crash
+                    return 2
+            self._reader = L.READ_RANGE_FN(_read)   # (kept alive: the library calls it until close)
+            rc = L.lib().chq_parquet_open_reader(int(size), self._reader, None, C.byref(self._h), err, len(err))
+        else:
+            if isinstance(source, (bytes, bytearray, memoryview)):
+                self._bytes = np.frombuffer(source, dtype=np.uint8)
+            else:
+                self._bytes = np.fromfile(source, dtype=np.uint8)
+            rc = L.lib().chq_parquet_open(self._bytes.ctypes.data, self._bytes.size, C.byref(self._h), err, len(err))
         if rc:
             raise ChqError(rc, err.value.decode(errors="replace"))
+
+    @property
+    def num_columns(self) -> int:
+        return L.lib().chq_parquet_num_columns(self._h)
+
+    @property
+    def column_names(self) -> List[str]:
+        return [L.lib().chq_parquet_column_name(self._h, i).decode() for i in range(self.num_columns)]
 
     @property
     def num_row_groups(self) -> int:
@@ -515,15 +545,23 @@ class ParquetFile:
                                                 C.byref(out.array), C.byref(out.schema))
         return _finish(ctx, rc, out, device_result)
 
-    def read_row_groups(self, first: int = 0, count: Optional[int] = None, *, ctx: Optional[Context] = None, device_result: bool = True):
-        """Row groups [first, first + count) as one batch each (`chq_parquet_read_row_groups`): decoded together, two host
-        synchronisations per call."""
+    def read_row_groups(self, first: int = 0, count: Optional[int] = None, *, ctx: Optional[Context] = None, device_result: bool = True,
+                        columns: Optional[Sequence] = None):
+        """Row groups [first, first + count) as one batch each (`chq_parquet_read_row_groups` / `chq_parquet_read_columns`):
+        decoded together, two host synchronisations per call.  `columns`: names or indices of the columns to decode, in the
+        order wanted (column pruning: only their chunks are fetched, uploaded and decoded); None = every column."""
         ctx = ctx or default_context()
         n = self.num_row_groups - first if count is None else count
         outs = (L.ArrowDeviceArray * max(n, 1))()
         schemas = (L.ArrowSchema * max(n, 1))()
-        rc = L.lib().chq_parquet_read_row_groups(ctx.handle, self._h, first, n, L.ARROW_DEVICE_ROCM if device_result else L.ARROW_DEVICE_CPU,
-                                                 outs, schemas)
+        dev = L.ARROW_DEVICE_ROCM if device_result else L.ARROW_DEVICE_CPU
+        if columns is None:
+            rc = L.lib().chq_parquet_read_row_groups(ctx.handle, self._h, first, n, dev, outs, schemas)
+        else:
+            names = self.column_names
+            idx = [names.index(c) if isinstance(c, str) else int(c) for c in columns]
+            arr = (C.c_int32 * max(1, len(idx)))(*idx)
+            rc = L.lib().chq_parquet_read_columns(ctx.handle, self._h, first, n, arr, len(idx), dev, outs, schemas)
         if rc:
             raise ChqError(rc, ctx.last_error())
         res = []

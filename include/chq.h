@@ -274,11 +274,24 @@ chq_status chq_ipc_describe(const uint8_t* stream, int64_t stream_len, char* buf
  * Scope: flat schemas; BOOLEAN, INT32, INT64, FLOAT, DOUBLE, BYTE_ARRAY annotated String; required / optional columns;
  * PLAIN and RLE_DICTIONARY / PLAIN_DICTIONARY (also mixed inside a chunk: the writers' dictionary fallback); data pages
  * V1 and V2; UNCOMPRESSED (what the reference's writers produce: create_sample_data.rs:222,
- * materialize_files_task.rs:128-133).  Everything else: CHQ_ERR_NOT_SUPPORTED, the message names the feature. */
+ * materialize_files_task.rs:128-133) and SNAPPY (what pyarrow / Spark / DuckDB write by default; the pages are inflated on
+ * the GPU).  Everything else (GZIP, ZSTD, LZ4, BROTLI pages; nested schemas; DELTA_* encodings): CHQ_ERR_NOT_SUPPORTED, the
+ * message names the feature. */
 typedef struct chq_parquet chq_parquet;
 /* Footer + page headers; no GPU, no context.  On failure *out is NULL and `err` (if given) receives the message. */
 chq_status chq_parquet_open(const uint8_t* file, int64_t file_len, chq_parquet** out, char* err, size_t err_len);
+/* The same over a RANGE READER instead of the whole file in memory: the reference reads Parquet through opendal ranges
+ * (read_files_task.rs:233-250: op.reader_with(path), ParquetRecordBatchStreamBuilder over it), i.e. the footer and then only
+ * the column chunks a query decodes.  `read(user, offset, length, dst)` must fill dst[0 .. length) with the file's bytes
+ * [offset, offset + length) and return 0; any other value fails the call.  Open reads the file's tail (footer) and nothing
+ * else; every read call then fetches exactly the column chunks it decodes, one `read` per chunk, from the calling thread.
+ * `read` / `user` must stay valid until chq_parquet_close. */
+typedef int (*chq_read_range_fn)(void* user, int64_t offset, int64_t length, uint8_t* dst);
+chq_status chq_parquet_open_reader(int64_t file_len, chq_read_range_fn read, void* user, chq_parquet** out, char* err, size_t err_len);
 void chq_parquet_close(chq_parquet* pq);
+int32_t chq_parquet_num_columns(const chq_parquet* pq);
+/* Name of column `column` (valid until chq_parquet_close), or NULL. */
+const char* chq_parquet_column_name(const chq_parquet* pq, int32_t column);
 int32_t chq_parquet_num_row_groups(const chq_parquet* pq);
 int64_t chq_parquet_row_group_num_rows(const chq_parquet* pq, int32_t row_group);
 /* "rows R row_groups G columns C" / "column <name> <physical> <required|optional> [utf8]" / "rg <i> rows <n>" /
@@ -292,6 +305,13 @@ chq_status chq_parquet_read_row_group(chq_ctx* ctx, const chq_parquet* pq, int32
  * group.  On failure nothing is returned. */
 chq_status chq_parquet_read_row_groups(chq_ctx* ctx, const chq_parquet* pq, int32_t first, int32_t count, int out_device,
                                        struct ArrowDeviceArray* outs, struct ArrowSchema* out_schemas);
+
+/* Column pruning (the reference's own TODO, DEV_NOTES.md:123): the same call for the `n_columns` columns listed in
+ * `columns` (indices into the file's schema, in the order the output batch should carry them; NULL = every column).  Only
+ * those columns' chunks are fetched (range reader), uploaded and decoded.  chq_ctx_last_stats afterwards: rows_in = rows
+ * decoded, bytes_read_alg = file bytes sent to the GPU, bytes_written_alg = Arrow bytes produced. */
+chq_status chq_parquet_read_columns(chq_ctx* ctx, const chq_parquet* pq, int32_t first, int32_t count, const int32_t* columns,
+                                    int32_t n_columns, int out_device, struct ArrowDeviceArray* outs, struct ArrowSchema* out_schemas);
 
 /* ---- Parquet write with the page encode on the GPU ---------------------------------------
  * Replaces the encode the reference does with the `parquet` crate behind project_record

@@ -89,6 +89,10 @@ pub struct chq_ipc_message {
     pub private_data: *mut c_void,
 }
 
+/// chq_read_range_fn: fill dst[0 .. length) with the file's bytes [offset, offset + length); 0 = ok.  The reference's side of it
+/// is an opendal reader (read_files_task.rs:233-250): `op.blocking().read_with(path).range(offset..offset + length)`.
+pub type chq_read_range_fn = Option<unsafe extern "C" fn(user: *mut c_void, offset: i64, length: i64, dst: *mut u8) -> c_int>;
+
 /// struct chq_parquet_image: a complete Parquet file in host memory
 #[repr(C)]
 pub struct chq_parquet_image {
@@ -192,7 +196,16 @@ extern "C" {
 
     // ---- Parquet scan, page decode on the GPU (read_files_task.rs:233-282) ----
     pub fn chq_parquet_open(file: *const u8, file_len: i64, out: *mut *mut chq_parquet, err: *mut c_char, err_len: usize) -> c_int;
+    pub fn chq_parquet_open_reader(
+        file_len: i64, read: chq_read_range_fn, user: *mut c_void, out: *mut *mut chq_parquet, err: *mut c_char, err_len: usize,
+    ) -> c_int;
     pub fn chq_parquet_close(pq: *mut chq_parquet);
+    pub fn chq_parquet_num_columns(pq: *const chq_parquet) -> i32;
+    pub fn chq_parquet_column_name(pq: *const chq_parquet, column: i32) -> *const c_char;
+    pub fn chq_parquet_read_columns(
+        ctx: *mut chq_ctx, pq: *const chq_parquet, first: i32, count: i32, columns: *const i32, n_columns: i32, out_device: c_int,
+        outs: *mut ArrowDeviceArray, out_schemas: *mut FFI_ArrowSchema,
+    ) -> c_int;
     pub fn chq_parquet_num_row_groups(pq: *const chq_parquet) -> i32;
     pub fn chq_parquet_row_group_num_rows(pq: *const chq_parquet, row_group: i32) -> i64;
     pub fn chq_parquet_describe(pq: *const chq_parquet, buf: *mut c_char, buf_len: usize) -> c_int;

@@ -42,6 +42,7 @@ def check(raw: bytes, ctx, device_result=True):
     f.close()
 
 
+@pytest.mark.parametrize("codec", ["none", "snappy"])
 @pytest.mark.parametrize("kw", [
     dict(), dict(use_dictionary=False), dict(data_page_version="2.0"), dict(use_dictionary=False, data_page_version="2.0"),
     dict(data_page_size=300), dict(data_page_size=300, use_dictionary=False), dict(row_group_size=1500, data_page_size=2000),
@@ -49,9 +50,11 @@ def check(raw: bytes, ctx, device_result=True):
 ])
 @pytest.mark.parametrize("nulls", [False, True])
 @pytest.mark.parametrize("strings", ["mixed", "unique", "few"])
-def test_row_groups_match_pyarrow(ctx, kw, nulls, strings):
+def test_row_groups_match_pyarrow(ctx, kw, nulls, strings, codec):
+    """the whole matrix once as the reference's writers leave their files (uncompressed) and once as everybody else's do
+    (snappy: pyarrow's default): the pages of a compressed chunk are inflated on the GPU (csrc/parquet_codec.hip)"""
     for n in [1, 63, 64, 65, 1000, 4097, 20_000]:
-        check(write_bytes(sample_table(n, seed=n, nulls=nulls, strings=strings), **kw), ctx)
+        check(write_bytes(sample_table(n, seed=n, nulls=nulls, strings=strings), compression=codec, **kw), ctx)
 
 
 def test_edge_cases(ctx):
@@ -69,6 +72,125 @@ def test_edge_cases(ctx):
     one_page = pa.table({"v": pa.array(rng.integers(0, 1000, 300_000).astype(np.int32)), "s": pa.array(["%05d" % v for v in rng.integers(0, 99999, 300_000)])})
     for kw in [dict(data_page_size=1 << 26), dict(data_page_size=1 << 26, use_dictionary=False)]:
         check(write_bytes(one_page, **kw), ctx)
+
+
+def test_snappy_pages_of_every_shape(ctx):
+    """what the inflate kernel has to get right beyond the matrix above: pages far larger than its 64 KiB ring of output
+    history, incompressible data (one literal per 64 KiB block), runs (copies with offset 1 that overlap themselves), pages
+    whose first element is a literal longer than the ring, V2 pages with uncompressed level sections, all-null columns"""
+    rng = np.random.default_rng(77)
+    n = 400_000
+    t = pa.table({
+        "noise": pa.array(rng.integers(-2**62, 2**62, n), type=pa.int64()),                      # incompressible
+        "zeros": pa.array(np.zeros(n, dtype=np.int32)),                                          # offset-1 copies
+        "ramp": pa.array((np.arange(n) // 1000).astype(np.int32)),                               # long matches
+        "text": pa.array(["the quick brown fox %d jumps over the lazy dog" % (v % 97) for v in range(n)]),
+        "opt": pa.array(rng.integers(0, 5, n).astype(np.float64), mask=rng.random(n) < 0.4),
+        "nulls": pa.array([None] * n, type=pa.int32()),
+    })
+    for kw in [dict(), dict(use_dictionary=False), dict(use_dictionary=False, data_page_size=1 << 24), dict(data_page_version="2.0"),
+               dict(data_page_version="2.0", use_dictionary=False, data_page_size=1 << 22), dict(row_group_size=150_000, data_page_size=4096)]:
+        check(write_bytes(t, compression="snappy", **kw), ctx)
+    check(write_bytes(sample_table(0), compression="snappy"), ctx)
+    check(write_bytes(sample_table(3000, seed=3, nulls=True), compression="snappy"), ctx, device_result=False)
+
+
+def test_column_pruning_uploads_only_the_selected_chunks(ctx):
+    """DEV_NOTES.md:123 (the reference's own TODO): a query that reads one column must not pay for the others -- a pruned
+    read of 1 of 3 same-width columns uploads about a third of the bytes, columns come back in the order asked for"""
+    n = 200_000
+    rng = np.random.default_rng(13)
+    t = pa.table({"a": pa.array(rng.integers(0, 2**31, n).astype(np.int32)), "b": pa.array(rng.random(n).astype(np.float32)),
+                  "c": pa.array(rng.integers(0, 2**31, n).astype(np.int32))})
+    for codec in ("none", "snappy"):
+        raw = write_bytes(t, compression=codec, use_dictionary=False, row_group_size=50_000)
+        f = chq.ParquetFile(raw)
+        assert f.column_names == ["a", "b", "c"] and f.num_columns == 3
+        full = f.read_row_groups(ctx=ctx)
+        up_all = ctx.last_stats()["bytes_read_alg"]
+        assert ctx.last_stats()["rows_in"] == n and ctx.last_stats()["bytes_written_alg"] == 12 * n
+        one = f.read_row_groups(ctx=ctx, columns=["b"])
+        up_one = ctx.last_stats()["bytes_read_alg"]
+        assert 0.30 * up_all < up_one < 0.37 * up_all, (up_one, up_all)
+        assert ctx.last_stats()["bytes_written_alg"] == 4 * n
+        two = f.read_row_groups(ctx=ctx, columns=[2, 0])
+        want = pq.ParquetFile(io.BytesIO(raw))
+        for g in range(f.num_row_groups):
+            w = want.read_row_group(g).to_batches()[0]
+            assert full[g].to_host().equals(w)
+            assert one[g].to_host().equals(w.select(["b"]))
+            assert two[g].to_host().equals(w.select(["c", "a"]))
+        with pytest.raises(chq.ChqError):
+            f.read_row_groups(ctx=ctx, columns=[3])
+        assert [b.num_columns for b in f.read_row_groups(ctx=ctx, columns=[])] == [0] * f.num_row_groups
+        f.close()
+
+
+def test_range_reader_fetches_the_footer_and_only_the_chunks_it_decodes(ctx):
+    """the reference reads through opendal ranges (read_files_task.rs:233-250): the library asks the caller's reader for the
+    file's tail at open and then for exactly the column chunks a call decodes -- never the whole file"""
+    t = sample_table(60_000, seed=21, nulls=True)
+    for codec in ("none", "snappy"):
+        raw = write_bytes(t, compression=codec, row_group_size=20_000)
+        f = chq.ParquetFile(None, reader=lambda off, ln: raw[off:off + ln], size=len(raw))
+        assert len(f.reads) <= 2 and sum(l for _, l in f.reads) <= 70_000 and f.reads[0][0] + f.reads[0][1] == len(raw)
+        assert f.num_row_groups == 3 and f.column_names == t.schema.names
+        f.reads.clear()
+        got = f.read_row_groups(1, 2, ctx=ctx, columns=["value1", "id"])
+        md = pq.ParquetFile(io.BytesIO(raw)).metadata
+        want_reads = []
+        for g in (1, 2):
+            for name in ("value1", "id"):
+                cm = md.row_group(g).column(t.schema.names.index(name))
+                first = cm.dictionary_page_offset if cm.dictionary_page_offset else cm.data_page_offset
+                want_reads.append((first, cm.total_compressed_size))
+        assert sorted(f.reads) == sorted(want_reads)                        # one read per selected chunk, nothing else
+        want = pq.ParquetFile(io.BytesIO(raw))
+        for k, g in enumerate((1, 2)):
+            assert got[k].to_host().equals(want.read_row_group(g).to_batches()[0].select(["value1", "id"]))
+        whole = f.read_row_groups(ctx=ctx)
+        assert [b.to_host() for b in whole] == [want.read_row_group(g).to_batches()[0] for g in range(3)]
+        f.close()
+    # a reader that fails, and one that returns short reads: a status, not a crash
+    raw = write_bytes(t, row_group_size=20_000)
+    calls = []
+
+    def flaky(off, ln):
+        calls.append(off)
+        if len(calls) > 1:
+            raise IOError("storage went away")
+        return raw[off:off + ln]
+    f = chq.ParquetFile(None, reader=flaky, size=len(raw))
+    with pytest.raises(chq.ChqError) as e:
+        f.read_row_groups(ctx=ctx)
+    assert e.value.code == 22 and "range reader" in str(e.value)
+    with pytest.raises(chq.ChqError):
+        chq.ParquetFile(None, reader=lambda off, ln: raw[off:off + ln - 1], size=len(raw))
+
+
+def test_damaged_snappy_pages_are_reported(ctx):
+    """compressed bytes overwritten: offsets beyond the output so far, literals running past the page, a wrong uncompressed
+    length -- the inflate kernel bounds every element and the call names the column"""
+    n = 50_000
+    rng = np.random.default_rng(5)
+    t = pa.table({"k": pa.array((np.arange(n) // 7).astype(np.int32)), "s": pa.array(["row %06d" % (v % 500) for v in range(n)])})
+    raw = write_bytes(t, compression="snappy", use_dictionary=False, data_page_size=8192)
+    md = pq.ParquetFile(io.BytesIO(raw)).metadata
+    reported = 0
+    for col in range(2):
+        cm = md.row_group(0).column(col)
+        for frac in (0.05, 0.3, 0.6, 0.9):
+            bad = bytearray(raw)
+            at = cm.data_page_offset + int(cm.total_compressed_size * frac)
+            bad[at:at + 48] = bytes(rng.integers(0, 256, 48, dtype=np.uint8))
+            try:
+                f = chq.ParquetFile(bytes(bad))
+                got = f.read_row_group(0, ctx=ctx)
+                assert got.num_rows == n       # (damage inside a literal decodes to different values: still a valid stream)
+            except chq.ChqError as e:
+                assert e.code in (22, 30), str(e)
+                reported += 1
+    assert reported >= 3
 
 
 def test_host_result_and_required_columns(ctx):
@@ -105,10 +227,11 @@ def test_scan_feeds_the_filter_kernels_without_leaving_hbm(ctx):
 
 def test_unsupported_features_say_so(ctx):
     t = sample_table(100, seed=2)
-    f = chq.ParquetFile(write_bytes(t, compression="snappy"))
-    with pytest.raises(chq.ChqError) as e:
-        f.read_row_group(0, ctx=ctx)
-    assert e.value.code == 30 and "codec" in str(e.value)
+    for codec, name in (("zstd", "ZSTD"), ("gzip", "GZIP"), ("lz4", "LZ4")):
+        f = chq.ParquetFile(write_bytes(t, compression=codec))
+        with pytest.raises(chq.ChqError) as e:
+            f.read_row_group(0, ctx=ctx)
+        assert e.value.code == 30 and "codec" in str(e.value) and name in str(e.value)
     f = chq.ParquetFile(write_bytes(pa.table({"d": pa.array([1, 2, 3], type=pa.date32())})))
     with pytest.raises(chq.ChqError) as e:
         f.read_row_group(0, ctx=ctx)

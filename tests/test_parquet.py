@@ -1,6 +1,7 @@
 """CPU tier of the Parquet scan: the library's footer / page-header reader (a hand-written Thrift
 compact-protocol reader, `csrc/parquet_meta.cpp`) against pyarrow's own view of files pyarrow wrote.  No GPU: only
 `chq_parquet_open` / `chq_parquet_describe`."""
+import ctypes as C
 import io
 
 import numpy as np
@@ -9,6 +10,7 @@ import pyarrow.parquet as pq
 import pytest
 
 import chapterhouseqe_amd as chq
+from chapterhouseqe_amd import _lib as L
 from tests.parquet_cases import sample_table, write_bytes
 
 
@@ -109,3 +111,55 @@ def test_corrupted_metadata_never_crashes_the_reader():
         except chq.ChqError:
             failed += 1
     assert opened + failed == 400 and failed > 20
+
+
+def _thrift_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7f
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _zigzag(v):
+    return _thrift_varint((v << 1) ^ (v >> 63))
+
+
+def test_sizes_near_int64_max_are_compared_by_subtraction():
+    """Page and chunk sizes come from an untrusted file.  `payload_at + compressed_size > size` wraps for a size near
+    INT64_MAX and would accept the page (read_files takes user files): every size in a page header or the footer that points
+    outside its container must be refused at open, with INVALID_ARGUMENT, before any cast to 32 bits."""
+    t = pa.table({"v": pa.array(np.arange(1000, dtype=np.int32))})
+    raw = write_bytes(t, use_dictionary=False, write_statistics=False)
+    md = pq.ParquetFile(io.BytesIO(raw)).metadata
+    at = md.row_group(0).column(0).data_page_offset
+    # the data page header: field 1 (type, i32), 2 (uncompressed size), 3 (compressed size) -- patch field 3 with a huge value
+    # by rebuilding the three leading fields (the rest of the header follows unchanged)
+    body = raw[at:]
+    assert body[0] == 0x15            # field 1, i32
+    p = 1
+    while body[p] & 0x80:
+        p += 1
+    p += 1
+    assert body[p] == 0x15            # field 2
+    q = p + 1
+    while body[q] & 0x80:
+        q += 1
+    q += 1
+    assert body[q] == 0x15            # field 3
+    r = q + 1
+    while body[r] & 0x80:
+        r += 1
+    r += 1
+    for evil in (2**62, 2**31 + 5, (1 << 63) - 1):
+        patched = raw[:at] + body[:q + 1] + _zigzag(evil) + body[r:]
+        # keep the footer where the file's tail says it is: only the page header grew
+        f = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.lib().chq_parquet_open(patched, len(patched), C.byref(f), err, len(err))
+        assert rc == 22, (rc, err.value)
+        assert not f.value
