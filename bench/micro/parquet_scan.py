@@ -2,7 +2,7 @@
 create_sample_data.rs) written with the reference's writer settings (uncompressed, dictionary with PLAIN fallback, V1 pages,
 1 Mi-row row groups), decoded (a) by pyarrow on the host CPU -- what read_files does today through the parquet crate --
 and (b) by chq.scan_parquet: column chunks uploaded as they lie in the file, pages decoded in HBM.
-usage: python bench/micro/parquet_scan.py [rows]"""
+usage: python bench/micro/parquet_scan.py [rows] [compression: none | snappy] [shape: sample | compressible]"""
 import io
 import sys
 import time
@@ -15,12 +15,21 @@ sys.path.insert(0, ".")
 import chapterhouseqe_amd as chq   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+codec = sys.argv[2] if len(sys.argv) > 2 else "none"
+shape = sys.argv[3] if len(sys.argv) > 3 else "sample"
 rng = np.random.default_rng(0)
 letters = rng.integers(ord("a"), ord("z") + 1, (n, 8), dtype=np.uint8)
+if shape == "compressible":   # few distinct letters per position, slowly changing: snappy finds matches (the sample data is random: it cannot)
+    letters = (ord("a") + ((np.arange(n)[:, None] // np.array([1 << 14, 1 << 12, 1 << 10, 1 << 8, 64, 16, 4, 1])) % 4)).astype(np.uint8)
 value1 = pa.Array.from_buffers(pa.utf8(), n, [None, pa.py_buffer((np.arange(n + 1, dtype=np.int32) * 8).tobytes()), pa.py_buffer(letters.tobytes())])
-t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "value1": value1, "value2": pa.array((rng.random(n) * 100).astype(np.float32))})
+v2 = (rng.random(n) * 100).astype(np.float32)
+if shape == "compressible":
+    v2 = np.round(v2)   # 101 distinct values
+t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "value1": value1, "value2": pa.array(v2)})
 buf = io.BytesIO()
-pq.write_table(t, buf, compression="none", row_group_size=1 << 20, data_page_size=1 << 20, dictionary_pagesize_limit=1 << 20)
+pq.write_table(t, buf, compression=codec, row_group_size=1 << 20, data_page_size=1 << 20, dictionary_pagesize_limit=1 << 20,
+               use_dictionary=shape != "compressible")
+print(f"compression {codec}, shape {shape}")
 raw = buf.getvalue()
 print(f"file: {len(raw) / 1e6:.1f} MB, {n} rows, {pq.ParquetFile(io.BytesIO(raw)).metadata.num_row_groups} row groups")
 

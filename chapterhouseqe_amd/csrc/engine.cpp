@@ -154,9 +154,11 @@ Context::~Context() {
   if (ev0) (void)hipEventDestroy(ev0);
   if (ev1) (void)hipEventDestroy(ev1);
   if (aux_fork) (void)hipEventDestroy(aux_fork);
+  for (hipEvent_t e : upload_events) (void)hipEventDestroy(e);
   for (int i = 0; i < kAuxStreams; ++i) { if (aux_join[i]) (void)hipEventDestroy(aux_join[i]); if (aux[i]) (void)hipStreamDestroy(aux[i]); }
   if (pinned) (void)hipHostFree(pinned);
   if (pinned_tbl) (void)hipHostFree(pinned_tbl);
+  if (pinned_sizes) (void)hipHostFree(pinned_sizes);
   if (pinned_io) (void)hipHostFree(pinned_io);
   if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
@@ -465,6 +467,24 @@ Batch to_host(Context& ctx, const Batch& b) {
   for (const Column& c : b.cols) o.cols.push_back(b.on_device ? copy_column(ctx, c, Dir::D2H) : c);
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   return o;
+}
+
+void GroupLite::set(size_t b, const Batch& r, const Batch& first, int device) {
+  rows[b] = r.nrows;
+  uint8_t f = 0;
+  if (r.on_device && r.device_id == device) f |= GL_ON_DEVICE;
+  if (r.nrows < 2) f |= GL_SHORT;
+  if (r.cols.size() != ncols) { flags[b] = (uint8_t)(f | GL_SCHEMA_DIFFERS); return; }
+  for (size_t i = 0; i < ncols; ++i) {
+    const Column& c = r.cols[i];
+    const Column& c0 = first.cols[i];
+    if (c.type != c0.type || c.width != c0.width || c.format != c0.format) f |= GL_SCHEMA_DIFFERS;
+    if (c.validity && c.null_count != 0) f |= GL_NULLS;
+    if (c.type == T_UTF8 && c.data == nullptr) f |= GL_NO_UTF8_DATA;
+    values0[b * ncols + i] = c.type == T_BOOL ? c.values : (const uint8_t*)c.values0();
+    data[b * ncols + i] = c.data;
+  }
+  flags[b] = f;
 }
 
 std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* aliases) {
@@ -987,6 +1007,7 @@ Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn
   size_t next_fixed = 0;
   bool first = true;
   if (ctx.opt_time_kernels && !ctx.ev0) { check_hip(hipEventCreate(&ctx.ev0), "hipEventCreate"); check_hip(hipEventCreate(&ctx.ev1), "hipEventCreate"); }
+
   do {
     FilterParams p{};
     p.nrows = mask_len;
@@ -1693,32 +1714,62 @@ Batch concat_device_batches(Context& ctx, const std::vector<Batch>& recs, size_t
   return cat;
 }
 
-// data bytes of every Utf8 column of every batch of a device-resident group (first / last offset read by one kernel)
-std::vector<std::vector<int64_t>> device_utf8_bytes(Context& ctx, const std::vector<Batch>& recs, const std::vector<int>& utf8_cols) {
-  const size_t nb = recs.size();
-  std::vector<std::vector<int64_t>> out(utf8_cols.size(), std::vector<int64_t>(nb, 0));
-  if (utf8_cols.empty()) return out;
-  const size_t words = (nb + 1) + nb;
-  ensure_pinned_table(ctx, words * 8 + nb * 8);
-  u64* h = (u64*)ctx.pinned_tbl;
+// data bytes of every Utf8 column of every batch of a device-resident group (first / last offset read by one kernel per
+// column).  Two steps: `issue` queues the kernels and the read-back, `finish` waits for them -- the one-launch path builds
+// its group table in between.
+struct Utf8Sizes {
+  std::vector<int> cols;
+  size_t nb = 0;
+  BufferPtr d_tbl;
+  int32_t* h_ends = nullptr;   // [cols][2 nb] in ctx.pinned_sizes
+};
+Utf8Sizes device_utf8_bytes_issue(Context& ctx, const std::vector<Batch>& recs, const GroupLite* lite, const std::vector<int>& utf8_cols) {
+  Utf8Sizes z;
+  z.cols = utf8_cols; z.nb = recs.size();
+  const size_t nb = z.nb, nu = utf8_cols.size();
+  if (nu == 0) return z;
+  const size_t words = (nb + 1) + nu * nb;                 // row_at, then one pointer table per column
+  const size_t need = words * 8 + nu * nb * 8;
+  if (ctx.pinned_sizes_bytes < need) {
+    if (ctx.pinned_sizes) (void)hipHostFree(ctx.pinned_sizes);
+    ctx.pinned_sizes = nullptr; ctx.pinned_sizes_bytes = 0;
+    check_hip(hipHostMalloc(&ctx.pinned_sizes, need + need / 4 + 4096, hipHostMallocDefault), "hipHostMalloc (utf8 sizes)");
+    ctx.pinned_sizes_bytes = need + need / 4 + 4096;
+  }
+  u64* h = (u64*)ctx.pinned_sizes;
   int64_t total = 0;
-  for (size_t b = 0; b < nb; ++b) { h[b] = (u64)total; total += recs[b].nrows; }
+  for (size_t b = 0; b < nb; ++b) { h[b] = (u64)total; total += lite ? lite->rows[b] : recs[b].nrows; }
   h[nb] = (u64)total;
-  auto d_tbl = make_device_buffer(words * 8 + nb * 8 + 16, ctx.device);
-  int32_t* d_ends = (int32_t*)((u64*)d_tbl->ptr + words);
-  int32_t* h_ends = (int32_t*)(h + words);
-  for (size_t k = 0; k < utf8_cols.size(); ++k) {
-    const int uc = utf8_cols[k];
-    pool_ranges(nb, 2048, [&](size_t i0, size_t i1) { for (size_t b = i0; b < i1; ++b) h[nb + 1 + b] = (u64)(uintptr_t)recs[b].cols[(size_t)uc].values0(); });
-    check_hip(hipMemcpyAsync(d_tbl->ptr, h, words * 8, hipMemcpyHostToDevice, ctx.stream), "upload offsets table");
+  z.d_tbl = make_device_buffer(need + 16, ctx.device);
+  z.h_ends = (int32_t*)(h + words);
+  for (size_t k = 0; k < nu; ++k) {
+    const size_t uc = (size_t)utf8_cols[k];
+    u64* tbl = h + nb + 1 + k * nb;
+    if (lite) for (size_t b = 0; b < nb; ++b) tbl[b] = (u64)(uintptr_t)lite->values0[b * lite->ncols + uc];
+    else pool_ranges(nb, 2048, [&](size_t i0, size_t i1) { for (size_t b = i0; b < i1; ++b) tbl[b] = (u64)(uintptr_t)recs[b].cols[uc].values0(); });
+  }
+  check_hip(hipMemcpyAsync(z.d_tbl->ptr, h, words * 8, hipMemcpyHostToDevice, ctx.stream), "upload offsets tables");
+  int32_t* d_ends = (int32_t*)((u64*)z.d_tbl->ptr + words);
+  for (size_t k = 0; k < nu; ++k) {
     ConcatParams cp{};
-    cp.nb = (int64_t)nb; cp.row_at = (const int64_t*)d_tbl->ptr; cp.src = (const u64*)d_tbl->ptr + nb + 1; cp.ends = d_ends;
+    cp.nb = (int64_t)nb; cp.row_at = (const int64_t*)z.d_tbl->ptr; cp.src = (const u64*)z.d_tbl->ptr + nb + 1 + k * nb; cp.ends = d_ends + 2 * k * nb;
     check_hip(launch_concat(cp, 1, 1, ctx.stream), "launch gather_ends_kernel");
-    check_hip(hipMemcpyAsync(h_ends, d_ends, nb * 8, hipMemcpyDeviceToHost, ctx.stream), "read back ends");
-    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
-    for (size_t b = 0; b < nb; ++b) out[k][b] = (int64_t)h_ends[2 * b + 1] - h_ends[2 * b];
+  }
+  check_hip(hipMemcpyAsync(z.h_ends, d_ends, nu * nb * 8, hipMemcpyDeviceToHost, ctx.stream), "read back ends");
+  return z;
+}
+std::vector<std::vector<int64_t>> device_utf8_bytes_finish(Context& ctx, const Utf8Sizes& z) {
+  std::vector<std::vector<int64_t>> out(z.cols.size(), std::vector<int64_t>(z.nb, 0));
+  if (z.cols.empty()) return out;
+  check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  for (size_t k = 0; k < z.cols.size(); ++k) {
+    const int32_t* e = z.h_ends + 2 * k * z.nb;
+    for (size_t b = 0; b < z.nb; ++b) out[k][b] = (int64_t)e[2 * b + 1] - e[2 * b];
   }
   return out;
+}
+std::vector<std::vector<int64_t>> device_utf8_bytes(Context& ctx, const std::vector<Batch>& recs, const std::vector<int>& utf8_cols) {
+  return device_utf8_bytes_finish(ctx, device_utf8_bytes_issue(ctx, recs, nullptr, utf8_cols));
 }
 }  // namespace
 
@@ -1727,19 +1778,19 @@ namespace {
 // path fills it directly and sets co->done, every other path returns per-batch outputs for the caller to join
 struct Coalesced { Batch out; std::vector<int64_t> rows; bool done = false; };
 std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                       const Expr& expr, bool out_on_device, Coalesced* co);
+                                       const Expr& expr, bool out_on_device, Coalesced* co, const GroupLite* lite, GroupSliced* sliced);
 }  // namespace
 
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                  const Expr& expr, bool out_on_device) {
-  return filter_records_impl(ctx, recs, aliases, expr, out_on_device, nullptr);
+                                  const Expr& expr, bool out_on_device, const GroupLite* lite, GroupSliced* sliced) {
+  return filter_records_impl(ctx, recs, aliases, expr, out_on_device, nullptr, lite, sliced);
 }
 
 Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record) {
+                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record, const GroupLite* lite) {
   if (recs.empty()) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "no record batches to coalesce"};
   Coalesced co;
-  std::vector<Batch> outs = filter_records_impl(ctx, recs, aliases, expr, out_on_device, &co);
+  std::vector<Batch> outs = filter_records_impl(ctx, recs, aliases, expr, out_on_device, &co, lite, nullptr);
   if (!co.done) {   // join the per-batch results on the host (general column kinds), then move them where they are wanted
     const chq_call_stats st = ctx.stats;
     std::vector<Batch> host;
@@ -1755,8 +1806,9 @@ Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, con
 
 namespace {
 std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                       const Expr& expr, bool out_on_device, Coalesced* co) {
+                                       const Expr& expr, bool out_on_device, Coalesced* co, const GroupLite* lite, GroupSliced* sliced) {
   const size_t nb = recs.size();
+  if (lite && (lite->rows.size() != nb || nb == 0 || lite->ncols != recs[0].cols.size())) lite = nullptr;
   auto per_batch_loop = [&]() {
     std::vector<Batch> outs;
     chq_call_stats acc{};
@@ -1897,12 +1949,25 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   };
 
   // ---- eligibility -----------------------------------------------------------------------------------
+  PhaseTimer pt("filter_records (one-launch path)");
   const size_t ncols = recs[0].cols.size();
   if (ncols == 0) return per_batch_loop();
   bool plain = (int)ncols <= MAX_OUT, same_schema = true, all_host = !recs[0].on_device;
   // `foldable`: device-resident, non-null, fixed-width or Utf8 columns -- short-string Utf8 columns can then be filtered
   // straight out of the batches by the one-launch path (their offsets and bytes per batch ride in the group table)
   bool foldable = (int)ncols <= MAX_OUT && ctx.opt_fold_utf8 && ctx.opt_group_fold;
+  bool has_bool = false, has_utf8 = false;
+  for (size_t i = 0; i < ncols; ++i) { has_bool |= recs[0].cols[i].type == T_BOOL; has_utf8 |= recs[0].cols[i].type == T_UTF8; }
+  if (lite && recs[0].on_device) {
+    // device-resident group: the facts were gathered per batch at import (GroupLite) -- one pass over nb bytes
+    uint8_t any = 0, all = 0xff;
+    for (uint8_t f : lite->flags) { any |= f; all &= f; }
+    if (any & (GroupLite::GL_SHORT | GroupLite::GL_SCHEMA_DIFFERS)) { if (any & GroupLite::GL_SHORT) return per_batch_loop(); same_schema = false; }
+    all_host = false;
+    const bool nulls = any & GroupLite::GL_NULLS;
+    plain = plain && !has_bool && !has_utf8 && !nulls;
+    foldable = foldable && (all & GroupLite::GL_ON_DEVICE) && !has_bool && !nulls && !(any & GroupLite::GL_NO_UTF8_DATA);
+  } else
   for (const Batch& r : recs) {
     if (r.cols.size() != ncols || r.nrows < 2) return per_batch_loop();
     all_host &= !r.on_device;
@@ -1919,22 +1984,29 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   std::vector<int> fold_utf8;                          // the Utf8 columns of a foldable group
   std::vector<std::vector<int64_t>> fold_bytes;        // their data bytes per batch
   std::vector<int64_t> fold_cap;
+  Utf8Sizes sizes_in_flight;
+  int64_t fold_rows_all = 0;
   if (!plain && foldable) {
     for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type == T_UTF8) fold_utf8.push_back((int)i);
-    int64_t rows_all = 0;
-    for (const Batch& r : recs) rows_all += r.nrows;
-    foldable = !fold_utf8.empty() && (int)fold_utf8.size() <= MAX_FOLD_UTF8 && rows_all < (1ll << 31) - 64;
-    if (foldable) {
-      fold_bytes = device_utf8_bytes(ctx, recs, fold_utf8);
-      for (const auto& per_batch : fold_bytes) {
-        int64_t cap = 0;
-        for (int64_t v : per_batch) cap += v;
-        fold_cap.push_back(cap);
-        foldable &= cap <= rows_all * 24 && cap < (1ll << 31) - 64;   // short strings that fit ONE output column
-      }
-    }
+    if (lite) for (int64_t r : lite->rows) fold_rows_all += r; else for (const Batch& r : recs) fold_rows_all += r.nrows;
+    foldable = !fold_utf8.empty() && (int)fold_utf8.size() <= MAX_FOLD_UTF8 && fold_rows_all < (1ll << 31) - 64;
+    // the batches' string sizes are read back from the device: queued here, awaited only after the predicate has been
+    // typed and the group table built (`finish_fold_sizes` below)
+    if (foldable) sizes_in_flight = device_utf8_bytes_issue(ctx, recs, lite, fold_utf8);
   }
-  const bool fold = !plain && foldable;
+  bool fold = !plain && foldable;
+  auto finish_fold_sizes = [&]() -> bool {   // false: long strings, or more than one output column can address
+    fold_bytes = device_utf8_bytes_finish(ctx, sizes_in_flight);
+    bool ok = true;
+    for (const auto& per_batch : fold_bytes) {
+      int64_t cap = 0;
+      for (int64_t v : per_batch) cap += v;
+      fold_cap.push_back(cap);
+      ok &= cap <= fold_rows_all * 24 && cap < (1ll << 31) - 64;   // short strings that fit ONE output column
+    }
+    return ok;
+  };
+  pt.mark("eligibility+utf8_sizes");
   if (!plain && !fold) {
     bool all_device = true;
     for (const Batch& r : recs) all_device &= r.on_device && r.device_id == ctx.device;
@@ -1955,6 +2027,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   }
   // a foldable group that turns out not to fit the one-launch path is joined on the device instead
   auto other_path = [&]() -> std::vector<Batch> {
+    if (!sizes_in_flight.cols.empty()) check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // (the size gather reads back into pinned memory the next call reuses)
     if (!fold) return per_batch_loop();
     try {
       return device_concat_path();
@@ -1965,6 +2038,12 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   };
   int64_t total_rows = 0, max_rows = 0;
   const bool host_in = !recs[0].on_device;
+  if (lite && !host_in) {   // (everything this loop checks per batch is in the flags reduced above)
+    for (int64_t r : lite->rows) { total_rows += r; max_rows = std::max(max_rows, r); }
+    bool all_dev = true;
+    for (uint8_t f : lite->flags) all_dev &= (f & GroupLite::GL_ON_DEVICE) != 0;
+    if (!all_dev || has_bool || (has_utf8 && !fold) || !(plain || fold)) return per_batch_loop();
+  } else
   for (const Batch& r : recs) {
     if (r.cols.size() != ncols || r.nrows < 2 || r.on_device == host_in) return per_batch_loop();
     for (size_t i = 0; i < ncols; ++i) {
@@ -1997,6 +2076,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
 
   ctx.stats = chq_call_stats{};
   ctx.stats.rows_in = total_rows;
+  pt.mark("typing");
 
   // ---- inputs: device pointers per batch and column ------------------------------------------------------
   // host batches are packed column-wise into one staging block per column and uploaded with one copy each
@@ -2019,6 +2099,8 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
       staged.push_back(db); staged.push_back(pack);
     }
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  } else if (lite) {
+    memcpy(in_ptr.v.data(), lite->values0.data(), nb * ncols * sizeof(const uint8_t*));
   } else {
     for (size_t b = 0; b < nb; ++b)
       for (size_t i = 0; i < ncols; ++i) in_ptr[b][i] = (const uint8_t*)recs[b].cols[i].values0();
@@ -2045,13 +2127,13 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   }
   if (tile_kind < 0) {   // the large tile unless padding every batch to a multiple of it idles more than a quarter of the lanes
     int64_t padded = 0;
-    for (const Batch& r : recs) padded += (r.nrows + kTileRows[0] - 1) / kTileRows[0] * kTileRows[0];
+    for (size_t b = 0; b < nb; ++b) { const int64_t r = lite ? lite->rows[b] : recs[b].nrows; padded += (r + kTileRows[0] - 1) / kTileRows[0] * kTileRows[0]; }
     tile_kind = padded * 4 <= total_rows * 5 ? 0 : 1;
   }
   const int64_t tile_rows = kTileRows[tile_kind];
   int64_t ntiles = 0;
   if (wpb > 0) ntiles = (wpb * (int64_t)nb + kWavesPerTile[tile_kind] - 1) / kWavesPerTile[tile_kind];
-  else for (const Batch& r : recs) ntiles += (r.nrows + tile_rows - 1) / tile_rows;
+  else for (size_t b = 0; b < nb; ++b) ntiles += ((lite ? lite->rows[b] : recs[b].nrows) + tile_rows - 1) / tile_rows;
   ensure_scratch(ctx, ntiles);
   Scratch* ds = dev_scratch(ctx);
 
@@ -2074,24 +2156,30 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   {
     u64* w = h_tbl;
     int64_t tile = 0;
+    auto utf8_data = [&](size_t b, size_t k) -> u64 {
+      return (u64)(uintptr_t)(lite ? lite->data[b * ncols + (size_t)fold_utf8[k]] : recs[b].cols[(size_t)fold_utf8[k]].data);
+    };
     for (size_t b = 0; b < nb; ++b) {
-      const int64_t rows = recs[b].nrows;
+      const int64_t rows = lite ? lite->rows[b] : recs[b].nrows;
       if (wpb > 0) {
         *w++ = (u64)rows;
         for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
         for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
-        for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = (u64)(uintptr_t)recs[b].cols[(size_t)fold_utf8[k]].data; }
+        for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = utf8_data(b, k); }
         continue;
       }
       for (int64_t r0 = 0; r0 < rows; r0 += tile_rows, ++tile) {
         *w++ = (u64)r0; *w++ = (u64)rows;
         for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
         for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
-        for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = (u64)(uintptr_t)recs[b].cols[(size_t)fold_utf8[k]].data; }
+        for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = utf8_data(b, k); }
       }
       h_idx[b] = tile - 1;   // rows >= 2: every batch owns at least one tile
     }
   }
+  pt.mark("table");
+  if (fold && !finish_fold_sizes()) return other_path();   // (long strings / too many bytes for one column: joined on the device)
+  pt.mark("utf8_sizes");
   auto d_tbl = make_device_buffer(bytes_tbl + bytes_idx + bytes_cnt + 16, ctx.device);
   check_hip(hipMemcpyAsync(d_tbl->ptr, h_tbl, bytes_tbl + bytes_idx, hipMemcpyHostToDevice, ctx.stream), "upload group table");
   u64* d_cnt = (u64*)((uint8_t*)d_tbl->ptr + bytes_tbl + bytes_idx);
@@ -2145,7 +2233,9 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   Scratch* hs = (Scratch*)ctx.pinned;
   check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
   check_hip(hipMemcpyAsync(h_cnt, d_cnt, bytes_cnt, hipMemcpyDeviceToHost, ctx.stream), "read back batch prefixes");
+  pt.mark("alloc+launch");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  pt.mark("kernel+readback");
   if (ctx.opt_time_kernels) { float ms = 0; check_hip(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1), "hipEventElapsedTime"); ctx.stats.kernel_ns = (int64_t)(ms * 1e6); }
   if (hs->err != ERR_NONE) return per_batch_loop();   // reports the earliest failing batch, as the reference's loop would
   (void)fold_status;
@@ -2190,6 +2280,16 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     int64_t prev = 0;
     for (size_t b = 0; b < nb; ++b) { co->rows.push_back((int64_t)h_cnt[b] - prev); prev = (int64_t)h_cnt[b]; }
     co->done = true;
+    return {};
+  }
+  if (sliced) {   // the caller cuts the dense buffers into Arrow structs itself (capi.cpp: one block for the whole group)
+    sliced->filled = true; sliced->on_device = out_on_device; sliced->device_id = out_on_device ? ctx.device : -1;
+    for (size_t i = 0; i < ncols; ++i) {
+      sliced->proto.push_back(empty_like(recs[0].cols[i]));
+      sliced->values.push_back(out_on_device ? dense[i] : host_dense[i]);
+      sliced->data.push_back(recs[0].cols[i].type == T_UTF8 ? (out_on_device ? dense_data[i] : host_data[i]) : BufferPtr());
+    }
+    sliced->ends.assign(h_cnt, h_cnt + nb);
     return {};
   }
   std::vector<Batch> outs(nb);

@@ -134,7 +134,15 @@ struct Context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // Parquet scan: the columns of a row group decode side by side (their per-page kernels are latency-bound, one wave per
   // page); created on first use, joined back into `stream` before anything is read back
-  static constexpr int kAuxStreams = 12;
+  static constexpr int kAuxStreams = 13;    // twelve for kernels + kCopyStream for uploads
+  // Uploads of the Parquet scan go through a stream of their own.  A copy from pageable host memory keeps the calling
+  // thread until the copy has RUN, and on a column's kernel stream it runs behind every kernel queued there: with a slow
+  // page decode on that stream (a 70 ms inflate) the host sat in the next upload instead of issuing the other columns' work,
+  // and the columns decoded one after the other.  On the copy stream an upload waits for earlier uploads only; the column's
+  // stream waits for it through an event.
+  static constexpr int kCopyStream = 12;
+  static constexpr int kKernelStreams = 12;
+  std::vector<hipEvent_t> upload_events;    // pool: one per column in flight (parquet_scan.cpp)
   hipStream_t aux[kAuxStreams] = {};
   hipEvent_t aux_fork = nullptr, aux_join[kAuxStreams] = {};
   bool aux_ready = false;           // every auxiliary stream and event exists (ensure_aux_streams)
@@ -145,6 +153,8 @@ struct Context {
   size_t pinned_bytes = 0;
   void* pinned_tbl = nullptr;              // pinned staging of a batch-group launch (tile table, per-batch prefixes)
   size_t pinned_tbl_bytes = 0;
+  void* pinned_sizes = nullptr;            // pinned staging of the Utf8 size gather of a group (in flight while the table is built)
+  size_t pinned_sizes_bytes = 0;
   void* pinned_io = nullptr;               // pinned staging of the small host-batch path: [inputs | outputs]
   size_t pinned_io_bytes = 0;
   BufferPtr dev_io;                        // its device twin
@@ -181,12 +191,35 @@ Batch filter_record(Context& ctx, const Batch& rec_dev, const std::vector<PlanCo
 // synchronisation).  False = outside its scope or an error was flagged: take the general path.
 bool filter_record_small_host(Context& ctx, const Batch& rec_host, const chq_table_aliases* aliases, const Expr& expr, Batch* result);
 bool filter_record_large_host(Context& ctx, const Batch& rec_host, const chq_table_aliases* aliases, const Expr& expr, Batch* result);
-// one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says
+// Per-batch facts of a group in flat arrays, gathered while the batches are imported (capi.cpp: the Arrow structs of 10^4
+// batches are ~10^5 dependent cache misses, taken once, on the pool's threads).  Later passes of a group call -- eligibility,
+// row totals, pointer tables -- read these arrays instead of walking the Batch objects again.
+struct GroupLite {
+  size_t ncols = 0;
+  std::vector<int64_t> rows;               // [nb]
+  std::vector<const uint8_t*> values0;     // [nb * ncols] Column::values0() (Boolean: the bitmap)
+  std::vector<const uint8_t*> data;        // [nb * ncols] Utf8 bytes
+  std::vector<uint8_t> flags;              // [nb] GL_*
+  enum : uint8_t { GL_NULLS = 1, GL_NO_UTF8_DATA = 2, GL_SCHEMA_DIFFERS = 4, GL_ON_DEVICE = 8, GL_SHORT = 16 };
+  void resize(size_t nb, size_t nc) { ncols = nc; rows.assign(nb, 0); values0.assign(nb * nc, nullptr); data.assign(nb * nc, nullptr); flags.assign(nb, 0); }
+  void set(size_t b, const Batch& r, const Batch& first, int device);
+};
+// The one-launch result of a group call before it is cut into per-batch Arrow structs: dense output buffers every batch's
+// output is a slice of (capi.cpp exports them from one block instead of ~20 allocations per batch).
+struct GroupSliced {
+  bool filled = false, on_device = false;
+  int device_id = -1;
+  std::vector<Column> proto;               // per column: name / format / type / width / nullable flag
+  std::vector<BufferPtr> values, data;     // per column: values (Utf8: joined offsets), Utf8 bytes
+  std::vector<int64_t> ends;               // [nb] exclusive end row of every batch in the dense output
+};
+// one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says.  `lite`
+// (optional): the batches' GroupLite; `sliced` (optional): filled instead of the returned vector when the one-launch path ran
 std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                  const Expr& expr, bool out_on_device);
+                                  const Expr& expr, bool out_on_device, const GroupLite* lite = nullptr, GroupSliced* sliced = nullptr);
 // the same, but ONE output batch holding every surviving row in input order (+ surviving rows per input batch)
 Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record);
+                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record, const GroupLite* lite = nullptr);
 Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_dev,
                      const std::vector<PlanColumn>& pcols);
 // filter_record + project_record in one kernel pass; false = outside its scope (or an error was flagged): run the two steps

@@ -45,22 +45,25 @@ struct PqDecodeParams {
 enum : uint32_t { PQ_CODEC_STORED = 0, PQ_CODEC_SNAPPY = 1 };
 enum : uint32_t { PQ_JOB_KEEP_LEVELS = 1 };   // with `page`: the column's definition levels are decoded (else only skipped)
 struct PqCodecJob {
-  uint32_t src_at, src_len;   // in the raw chunk buffer (the chunk as it lies in the file)
-  uint32_t dst_at, dst_len;   // in the image; dst_at is a multiple of 16, dst_len is what the page header promises
+  const uint8_t* raw;         // the chunk as it lies in the file (in HBM)
+  uint8_t* image;             // the chunk's uncompressed image
+  PqPageDesc* pages;          // the chunk's page descriptors (in HBM)
+  uint32_t* err;              // the column's error word
+  uint32_t src_at, src_len;   // in `raw`
+  uint32_t dst_at, dst_len;   // in `image`; dst_at is a multiple of 16, dst_len is what the page header promises
   uint32_t codec;             // PQ_CODEC_*
   int32_t page;               // >= 0: a V1 data page of an optional column -- [4-byte length][levels][values] can only be told
                               // apart after inflation: the kernel fills levels_at / levels_len / values_at / values_len of pages[page]
   uint32_t flags;             // PQ_JOB_*
   uint32_t pad;
 };
+// One launch serves every compressed page of every column and row group of a call's wave (jobs carry their own buffers):
+// a page is a serial chain, so the pages in flight are the parallelism -- per-column launches on the columns' streams left the
+// twenty slowest pages of a twenty-row-group file sharing the handful of hardware queues the streams map to.
 struct PqCodecParams {
-  const uint8_t* raw;
-  uint8_t* image;
   const PqCodecJob* jobs;
   int32_t n_jobs;
   int32_t pad;
-  PqPageDesc* pages;
-  uint32_t* err;
 };
 hipError_t pq_launch_inflate(const PqCodecParams& p, hipStream_t s);
 

@@ -1,6 +1,7 @@
 // parquet_scan.cpp -- orchestration of the GPU page decode (parquet.hip) for one row group.  See parquet.hpp for scope.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 
 #include "engine.hpp"
 #include "parquet.hpp"
@@ -66,6 +67,31 @@ BufferPtr upload(Context& ctx, hipStream_t stream, const std::vector<T>& v, Colu
 }  // namespace
 
 namespace {
+// The stream of column `ci` of the `j`-th row group of a wave.  (ci + j * columns) % 12 put the same column of consecutive
+// row groups on 12 / gcd(columns, 12) ... streams -- three columns: the string column of twenty row groups shared FOUR streams,
+// and its pages (the slow ones: serial walks, serial inflates) queued five deep.  7 and 5 are coprime with 12: the columns of one
+// row group get distinct streams, and one column visits all twelve over twelve row groups.
+inline hipStream_t column_stream(Context& ctx, size_t ci, size_t j) { return ctx.aux[(ci * 7 + j * 5) % Context::kKernelStreams]; }
+
+// the k-th upload event of this wave (created on first use, kept with the context)
+hipEvent_t upload_event(Context& ctx, size_t k) {
+  while (ctx.upload_events.size() <= k) {
+    hipEvent_t e = nullptr;
+    check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    ctx.upload_events.push_back(e);
+  }
+  return ctx.upload_events[k];
+}
+
+// What phase A of a wave collects before anything is launched: the inflate jobs of every compressed page, and per column the
+// closure that queues its decode kernels (they run behind the wave's ONE inflate launch).
+struct WaveLaunch {
+  std::vector<PqCodecJob> jobs;
+  struct Col { hipStream_t stream; hipEvent_t uploaded; bool compressed; std::function<void()> launch; };
+  std::vector<Col> cols;
+  size_t n_events = 0;
+};
+
 struct RowGroupJob {   // one row group between its two phases
   int64_t rows = 0;
   std::vector<ColumnWork> work;
@@ -74,7 +100,7 @@ struct RowGroupJob {   // one row group between its two phases
 };
 
 // ---- phase A: everything up to the Utf8 offsets, the columns side by side on the auxiliary streams (already forked) -----
-void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, size_t stream_shift, const std::vector<int>& sel) {
+void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, size_t stream_shift, const std::vector<int>& sel, WaveLaunch& wave) {
   if (row_group < 0 || row_group >= (int)f.row_groups.size()) malformed("row group " + std::to_string(row_group) + " of " + std::to_string(f.row_groups.size()));
   const PqRowGroup& rg = f.row_groups[row_group];
   const int64_t rows = rg.num_rows;
@@ -86,7 +112,8 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
   job.hs.assign(nc + 1, Scalars{});
   Scalars* dscal = (Scalars*)job.scal->ptr;   // (allocated and zeroed by the caller, on ctx.stream, before the streams forked)
   for (size_t ci = 0; ci < nc; ++ci) {
-    const hipStream_t cstream = ctx.aux[(ci + stream_shift) % Context::kAuxStreams];
+    const hipStream_t cstream = column_stream(ctx, ci, stream_shift);   // the column's kernels
+    const hipStream_t ustream = ctx.aux[Context::kCopyStream];          // every upload of the call (see engine.hpp)
     const PqColumnSchema& cs = f.columns[(size_t)sel[ci]];
     const PqColumnChunk& cc = rg.columns[(size_t)sel[ci]];
     ColumnWork& w = work[ci];
@@ -137,8 +164,8 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       chunk_pages = &w.pages;
     }
     BufferPtr raw = make_device_buffer((size_t)csize + 64, ctx.device);
-    if (csize > 0) check_hip(hipMemcpyAsync(raw->ptr, chunk_host, (size_t)csize, hipMemcpyHostToDevice, cstream), "upload column chunk");
-    check_hip(hipMemsetAsync((uint8_t*)raw->ptr + csize, 0, 64, cstream), "memset");
+    if (csize > 0) check_hip(hipMemcpyAsync(raw->ptr, chunk_host, (size_t)csize, hipMemcpyHostToDevice, ustream), "upload column chunk");
+    check_hip(hipMemsetAsync((uint8_t*)raw->ptr + csize, 0, 64, ustream), "memset");
     w.uploaded = csize;
     if (!compressed) w.chunkb = raw; else w.rawb = raw;   // (compressed: chunkb = the uncompressed image, allocated below)
 
@@ -247,19 +274,38 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
     }
     if (row_at != rows) malformed("pages of column '" + cs.name + "' hold " + std::to_string(row_at) + " rows, the row group has " + std::to_string(rows));
     const int n_pages = (int)descs.size();
-    w.pages_dev = upload(ctx, cstream, descs, w);
-    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_nonnull, w);
-    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, cstream, h_base, w);
+    w.pages_dev = upload(ctx, ustream, descs, w);
+    w.nonnull = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, ustream, h_nonnull, w);
+    w.value_base = w.has_levels ? make_device_buffer((size_t)n_pages * 4 + 16, ctx.device) : upload(ctx, ustream, h_base, w);
     w.host_values = rows;
-    if (compressed) {   // inflate every page into the image; the decode kernels below are queued behind it on the same stream
+    // (every upload of the column is queued before its first kernel: the column's stream then waits ONCE, on one event)
+    auto plain_dev = upload(ctx, ustream, plain_list, w), dict_dev = upload(ctx, ustream, dict_list, w), rle_dev = upload(ctx, ustream, rle_list, w);
+    w.keep.push_back(plain_dev); w.keep.push_back(dict_dev); w.keep.push_back(rle_dev);
+    if (w.byte_array && !dict_list.empty() && !compressed) {
+      // The dictionary page is ONE page: on the GPU a single workgroup would walk its length prefixes (5 ms for 1 MB of
+      // ragged strings).  The host has the bytes and walks them in ~0.2 ms while it prepares the launches.
+      std::vector<uint32_t> h_src(dict_count), h_len(dict_count);
+      const uint8_t* dp = chunk_host + dict_at;
+      uint64_t pos = 0;
+      for (uint32_t i = 0; i < dict_count; ++i) {
+        if (pos + 4 > dict_len) malformed("dictionary page of column '" + cs.name + "' ends inside an entry");
+        uint32_t l; memcpy(&l, dp + pos, 4);
+        if ((uint64_t)l > dict_len - pos - 4) malformed("dictionary entry of column '" + cs.name + "' runs past its page");
+        h_src[i] = dict_at + (uint32_t)pos + 4; h_len[i] = l;
+        pos += 4 + (uint64_t)l;
+      }
+      w.dict_src = upload(ctx, ustream, h_src, w);
+      w.dict_len = upload(ctx, ustream, h_len, w);
+    }
+    const hipEvent_t ev_uploaded = upload_event(ctx, wave.n_events++);
+    check_hip(hipEventRecord(ev_uploaded, ustream), "hipEventRecord(upload)");
+    if (compressed) {   // every page is inflated into the image by the wave's one inflate launch (parquet_read_row_groups)
       w.chunkb = make_device_buffer((size_t)image_at + 64, ctx.device);
-      check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + image_at, 0, 64, cstream), "memset");
-      auto jobs_dev = upload(ctx, cstream, jobs, w);
-      w.keep.push_back(jobs_dev);
-      PqCodecParams cp{};
-      cp.raw = (const uint8_t*)w.rawb->ptr; cp.image = (uint8_t*)w.chunkb->ptr; cp.jobs = (const PqCodecJob*)jobs_dev->ptr;
-      cp.n_jobs = (int32_t)jobs.size(); cp.pages = (PqPageDesc*)w.pages_dev->ptr; cp.err = &dscal[ci].err;
-      check_hip(pq_launch_inflate(cp, cstream), "launch pq_inflate_kernel");
+      check_hip(hipMemsetAsync((uint8_t*)w.chunkb->ptr + image_at, 0, 64, ustream), "memset");
+      for (PqCodecJob& j : jobs) {
+        j.raw = (const uint8_t*)w.rawb->ptr; j.image = (uint8_t*)w.chunkb->ptr; j.pages = (PqPageDesc*)w.pages_dev->ptr; j.err = &dscal[ci].err;
+        wave.jobs.push_back(j);
+      }
     }
 
     PqDecodeParams p{};
@@ -268,6 +314,8 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
     p.total_values = &dscal[ci].total_values; p.err = &dscal[ci].err;
     p.dict_at = dict_at; p.dict_len = dict_len; p.dict_count = dict_count;
     if (rows == 0 || n_pages == 0) continue;   // (an empty row group: phase B builds empty columns)
+    // the column's decode kernels, queued once the wave's uploads and inflate launch are in place
+    wave.cols.push_back(WaveLaunch::Col{cstream, ev_uploaded, compressed, [=, &ctx, &w]() mutable {
     if (w.has_levels) {
       w.valid8 = make_device_buffer((size_t)rows + 64, ctx.device);
       w.row_val = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
@@ -277,29 +325,12 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
       check_hip(pq_launch_rowval(p, cstream), "launch pq_rowval_kernel");
     }
     // dense values: at most `rows` of them
-    auto plain_dev = upload(ctx, cstream, plain_list, w), dict_dev = upload(ctx, cstream, dict_list, w), rle_dev = upload(ctx, cstream, rle_list, w);
-    w.keep.push_back(plain_dev); w.keep.push_back(dict_dev); w.keep.push_back(rle_dev);
     if (w.byte_array) {
       w.vsrc = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
       w.vlen = make_device_buffer((size_t)rows * 4 + 64, ctx.device);
       p.vsrc = (uint32_t*)w.vsrc->ptr; p.vlen = (uint32_t*)w.vlen->ptr;
       if (!dict_list.empty()) {
-        // The dictionary page is ONE page: on the GPU a single workgroup would walk its length prefixes (5 ms for 1 MB of
-        // ragged strings).  The host has the bytes and walks them in ~0.2 ms while it prepares the launches.
-        if (!compressed) {
-          std::vector<uint32_t> h_src(dict_count), h_len(dict_count);
-          const uint8_t* dp = chunk_host + dict_at;
-          uint64_t pos = 0;
-          for (uint32_t i = 0; i < dict_count; ++i) {
-            if (pos + 4 > dict_len) malformed("dictionary page of column '" + cs.name + "' ends inside an entry");
-            uint32_t l; memcpy(&l, dp + pos, 4);
-            if ((uint64_t)l > dict_len - pos - 4) malformed("dictionary entry of column '" + cs.name + "' runs past its page");
-            h_src[i] = dict_at + (uint32_t)pos + 4; h_len[i] = l;
-            pos += 4 + (uint64_t)l;
-          }
-          w.dict_src = upload(ctx, cstream, h_src, w);
-          w.dict_len = upload(ctx, cstream, h_len, w);
-        } else {   // the page is only readable after inflation: one workgroup walks it on the device
+        if (compressed) {   // the page is only readable after inflation: one workgroup walks it on the device
           w.dict_src = make_device_buffer((size_t)dict_count * 4 + 16, ctx.device);
           w.dict_len = make_device_buffer((size_t)dict_count * 4 + 16, ctx.device);
           PqDecodeParams dpw = p;
@@ -342,6 +373,7 @@ void phase_a(Context& ctx, const PqFile& f, int row_group, RowGroupJob& job, siz
         check_hip(pq_launch_dict_fixed(p, (int)dict_list.size(), cstream), "launch pq_dict_fixed_kernel");
       }
     }
+    }});
   }
 }
 
@@ -355,7 +387,7 @@ Batch phase_b(Context& ctx, RowGroupJob& job, size_t stream_shift) {
   out.on_device = true; out.device_id = ctx.device; out.nrows = rows;
   const int grid = ctx.num_cus * 8;
   for (size_t ci = 0; ci < nc; ++ci) {
-    const hipStream_t cstream = ctx.aux[(ci + stream_shift) % Context::kAuxStreams];
+    const hipStream_t cstream = column_stream(ctx, ci, stream_shift);
     ColumnWork& w = work[ci];
     if (hs[ci].err) malformed(std::string(hs[ci].err == PQ_ERR_CODEC ? "compressed pages" : hs[ci].err == PQ_ERR_LEVELS ? "definition levels" : "values") + " of column '" + w.schema->name + "' are malformed");
     Column o;
@@ -445,14 +477,33 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       check_hip(hipMemsetAsync(job.scal->ptr, 0, sizeof(Scalars) * (sel.size() + 1), ctx.stream), "memset");
     }
     fork_streams(ctx);
-    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j * sel.size(), sel);
+    WaveLaunch wave;
+    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j, sel, wave);
+    BufferPtr jobs_dev;
+    hipEvent_t ev_inflated = nullptr;
+    if (!wave.jobs.empty()) {   // ONE inflate launch for every compressed page of the wave, behind the last upload
+      const hipStream_t ustream = ctx.aux[Context::kCopyStream];
+      auto keep = std::make_shared<std::vector<PqCodecJob>>(std::move(wave.jobs));
+      jobs_dev = make_device_buffer(keep->size() * sizeof(PqCodecJob) + 16, ctx.device);
+      check_hip(hipMemcpyAsync(jobs_dev->ptr, keep->data(), keep->size() * sizeof(PqCodecJob), hipMemcpyHostToDevice, ustream), "upload inflate jobs");
+      jobs.front().work.front().host_keep.push_back(keep);
+      PqCodecParams cp{};
+      cp.jobs = (const PqCodecJob*)jobs_dev->ptr; cp.n_jobs = (int32_t)keep->size();
+      check_hip(pq_launch_inflate(cp, ustream), "launch pq_inflate_kernel");
+      ev_inflated = upload_event(ctx, wave.n_events++);
+      check_hip(hipEventRecord(ev_inflated, ustream), "hipEventRecord(inflate)");
+    }
+    for (WaveLaunch::Col& c : wave.cols) {
+      check_hip(hipStreamWaitEvent(c.stream, c.compressed ? ev_inflated : c.uploaded, 0), "hipStreamWaitEvent(upload)");
+      c.launch();
+    }
     join_streams(ctx);
     for (RowGroupJob& job : jobs)
       if (!job.work.empty()) check_hip(hipMemcpyAsync(job.hs.data(), job.scal->ptr, sizeof(Scalars) * job.work.size(), hipMemcpyDeviceToHost, ctx.stream), "read back");
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
     fork_streams(ctx);
     for (size_t j = 0; j < jobs.size(); ++j) {
-      outs.push_back(phase_b(ctx, jobs[j], j * sel.size()));
+      outs.push_back(phase_b(ctx, jobs[j], j));
       // (chq_call_stats of a scan: rows decoded, file bytes sent to the GPU, Arrow bytes produced)
       ctx.stats.rows_in += jobs[j].rows; ctx.stats.rows_out += jobs[j].rows;
       for (const ColumnWork& w : jobs[j].work) ctx.stats.bytes_read_alg += w.uploaded;

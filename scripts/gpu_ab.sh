@@ -6,7 +6,7 @@ rm -f gpurun_out/ab.log
 for rep in 1 2; do
 for which in head new; do
   if [ $which = head ]; then export CHQ_LIB_PATH=$PWD/bench/ab/libchq_head.so; else unset CHQ_LIB_PATH; fi
-  for c in "config2 value2>10" "config3 compound" "100k-row" "10k-row"; do
+  for c in ${AB_CASES:-"config2 value2>10" "config3 compound" "100k-row" "10k-row" "12 500 x 10k-row" "config5-shape"}; do
     echo "== $which | $c" >> gpurun_out/ab.log
     timeout -k 10 300 python bench_configs.py --steps 7 --only "$c" >> gpurun_out/ab.log 2>&1 || echo "FAILED" >> gpurun_out/ab.log
   done

@@ -4,7 +4,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/parquet_prof; rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/t -o r -- python3 bench/micro/parquet_scan.py 20000000 > $OUT/run.log 2>&1 || echo "trace failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/t -o r -- python3 bench/micro/parquet_scan.py ${1:-20000000} ${2:-none} ${3:-sample} > $OUT/run.log 2>&1 || echo "trace failed"
 tail -4 $OUT/run.log
 python3 scripts/rocpd_summary.py $OUT/t pq_ > $OUT/kernels.json
 python3 - <<PY

@@ -98,8 +98,8 @@ def test_minus_extension_fuzz_vs_oracle(minus_ctx, n, tile_kind):
     for _ in range(20):
         outcomes[check_same(minus_ctx, rec, al, random_numeric(rng, 3, ops=ops), "value")] += 1
     for _ in range(6):
-        cols = FAMILIES[int(rng.integers(0, len(FAMILIES)))]
-        sql = f"{random_numeric(rng, 2, cols, ops)} {rng.choice(['<', '>=', '=', '<>'])} {random_numeric(rng, 1, cols, ops)}"
+        cols, lits = pick_family(rng)
+        sql = f"{random_numeric(rng, 2, cols, ops, lits=lits)} {rng.choice(['<', '>=', '=', '<>'])} {random_numeric(rng, 1, cols, ops, lits=lits)}"
         outcomes[check_same(minus_ctx, rec, al, sql, "filter")] += 1
     minus_ctx.set_option("tile_kind", -1)
     assert outcomes["ok"] >= 12 and outcomes["unsupported"] == 0, outcomes
@@ -127,22 +127,28 @@ def test_minus_stays_rejected_without_the_option(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- fuzz vs oracle
-def make_batch(n, seed, nulls=True):
+def make_batch(n, seed, nulls=True, tame=False):
+    """`tame`: integer columns hold small magnitudes, so that sums and products of two or three of them stay inside their
+    type -- checked arithmetic (arrow's add / mul fail the whole batch on the first overflow) then mostly computes VALUES for
+    the fuzzers to compare; the full-range form keeps the boundary values (and ends most arithmetic in an overflow error)"""
     rng = np.random.default_rng(seed)
 
     def m(p):
         return (rng.random(n) < p) if nulls and n else None
 
+    def ints(lo, hi, tlo, thi, dtype):
+        return rng.integers(tlo, thi, n).astype(dtype) if tame else rng.integers(lo, hi, n).astype(dtype)
+
     words = np.array(["", "a", "ab", "abc", "b", "zeta", "a much longer string value that spans more than sixty-four bytes of utf8 text ..."])
     cols = {
-        "i8": pa.array(rng.integers(-128, 128, n).astype(np.int8)),
-        "i16": pa.array(rng.integers(-3000, 3000, n).astype(np.int16), mask=m(0.1)),
-        "i32": pa.array(rng.integers(-100000, 100000, n).astype(np.int32)),
-        "i64": pa.array(rng.integers(-10**12, 10**12, n).astype(np.int64), mask=m(0.05)),
-        "u8": pa.array(rng.integers(0, 256, n).astype(np.uint8)),
-        "u16": pa.array(rng.integers(0, 65536, n).astype(np.uint16)),
-        "u32": pa.array(rng.integers(0, 2**32, n).astype(np.uint32), mask=m(0.1)),
-        "u64": pa.array(rng.integers(0, 2**63, n).astype(np.uint64)),
+        "i8": pa.array(ints(-128, 128, -5, 6, np.int8)),
+        "i16": pa.array(ints(-3000, 3000, -30, 31, np.int16), mask=m(0.1)),
+        "i32": pa.array(ints(-100000, 100000, -1000, 1001, np.int32)),
+        "i64": pa.array(ints(-10**12, 10**12, -10**6, 10**6, np.int64), mask=m(0.05)),
+        "u8": pa.array(ints(0, 256, 0, 6, np.uint8)),
+        "u16": pa.array(ints(0, 65536, 0, 40, np.uint16)),
+        "u32": pa.array(ints(0, 2**32, 0, 1500, np.uint32), mask=m(0.1)),
+        "u64": pa.array(ints(0, 2**63, 0, 10**6, np.uint64)),
         "f32": pa.array((rng.random(n) * 200 - 100).astype(np.float32), mask=m(0.1)),
         "f64": pa.array(rng.random(n) * 2e6 - 1e6),
         "small": pa.array(rng.integers(1, 9, n).astype(np.int32)),
@@ -155,34 +161,82 @@ def make_batch(n, seed, nulls=True):
 
 
 NUMERIC = ["i8", "i16", "i32", "i64", "u8", "u16", "u32", "u64", "f32", "f64", "small"]
-# column families that the coercion table (compute_value.rs:350-431) can combine without an error
-FAMILIES = [["i8", "i16", "i32", "small"], ["i8", "i16", "i32", "u8", "u16", "f32", "small"], ["u8", "u16", "u32"],
-            ["i8", "i16", "i32", "u8", "u16", "u32", "i64", "small"], ["f32", "f64", "i32", "u32", "i64", "u64"], NUMERIC]
+# Column families in which EVERY pair of types -- and every pair of intermediate result types -- has a common type in the
+# coercion table (compute_value.rs:350-431), with the literal kinds that coerce against all of them ("i": an integer literal
+# is Int32, "f": a decimal literal is Float32): expressions drawn from one family evaluate instead of ending in
+# UnsupportedTypeCoersion.  The last entry is the old free-for-all (mostly static errors), kept with a small weight.
+FAMILIES = [
+    (["i8", "i16", "i32", "small", "i64"], "i"),
+    (["u8", "u16", "u32", "u64"], ""),
+    (["u8", "u16", "i32", "i64", "small"], "i"),
+    (["f32", "i8", "i16", "i32", "small"], "if"),
+    (["f32", "i16", "i32", "u8", "small"], "if"),
+    (["f32", "u8", "u16", "u32"], "f"),
+    (["f64", "f32"], "if"),
+    (["f64", "i32", "i64", "small"], "i"),
+    (["f64", "u8", "u32", "u64"], ""),
+    (NUMERIC, "if"),
+]
+FAMILY_WEIGHTS = np.array([3, 2, 2, 3, 2, 2, 2, 2, 1, 1], dtype=float) / 20.0
+_INT_NONZERO = {"small"}          # integer columns that never hold 0: safe divisors
+_FLOATS = {"f32", "f64"}
 
 
-def random_numeric(rng, depth, cols=None, ops=("+", "*", "/", "%", "+", "/")):
+def pick_family(rng):
+    return FAMILIES[int(rng.choice(len(FAMILIES), p=FAMILY_WEIGHTS))]
+
+
+def random_numeric(rng, depth, cols=None, ops=("+", "*", "/", "%", "+", "/"), lits="if", wild=0.1):
+    """a numeric expression over one family.  With probability 1 - `wild` the operators are chosen so that the expression
+    cannot fail on a tame batch for a trivial reason: integer `/` and `%` take a non-zero divisor (a literal or `small`),
+    `*` of integers multiplies by a literal or `small`"""
     if cols is None:
-        cols = FAMILIES[int(rng.integers(0, len(FAMILIES)))]
-    floaty = "f32" in cols or "f64" in cols
-    if depth == 0 or rng.random() < 0.3:
-        r = rng.random()
-        if r < 0.75:
-            return rng.choice(cols)
-        if r < 0.9 or not floaty:
-            return str(int(rng.integers(1, 50)))
+        cols, lits = pick_family(rng)
+    cols = list(cols)
+    careful = rng.random() >= wild
+
+    def literal():
+        kinds = [k for k in lits]
+        if not kinds:
+            return None
+        if str(rng.choice(kinds)) == "i" or not (set(cols) & _FLOATS):
+            return str(int(rng.integers(1, 9))) if "i" in kinds else "%.2f" % (rng.random() * 10 + 0.5)
         return "%.2f" % (rng.random() * 10 + 0.5)
-    op = rng.choice(list(ops))
-    l, r = random_numeric(rng, depth - 1, cols, ops), random_numeric(rng, depth - 1, cols, ops)
-    e = f"{l} {op} {r}"
-    return f"({e})" if rng.random() < 0.5 else e
+
+    def leaf():
+        lit = literal()
+        if lit is not None and rng.random() >= 0.75:
+            return lit
+        return str(rng.choice(cols))
+
+    def safe_factor():   # a right operand that neither is zero nor blows a small integer type up
+        lit = literal()
+        cand = [c for c in cols if c in _INT_NONZERO] + ([lit] if lit is not None else [])
+        return str(rng.choice(cand)) if cand else None
+
+    def gen(d):
+        if d == 0 or rng.random() < 0.3:
+            return leaf()
+        op = str(rng.choice(list(ops)))
+        left = gen(d - 1)
+        floaty = bool(set(cols) & _FLOATS) and all(c in _FLOATS for c in cols if c in left.split())
+        if careful and op in ("*", "/", "%") and not floaty:
+            right = safe_factor()
+            if right is None:
+                op, right = "+", gen(d - 1)
+        else:
+            right = gen(d - 1)
+        e = f"{left} {op} {right}"
+        return f"({e})" if rng.random() < 0.5 else e
+    return gen(depth)
 
 
 def random_predicate(rng, depth):
     if depth == 0 or rng.random() < 0.35:
         r = rng.random()
         if r < 0.6:
-            cols = FAMILIES[int(rng.integers(0, len(FAMILIES)))]
-            return f"{random_numeric(rng, 2, cols)} {rng.choice(['<', '<=', '>', '>=', '=', '<>'])} {random_numeric(rng, 1, cols)}"
+            cols, lits = pick_family(rng)
+            return f"{random_numeric(rng, 2, cols, lits=lits)} {rng.choice(['<', '<=', '>', '>=', '=', '<>'])} {random_numeric(rng, 1, cols, lits=lits)}"
         if r < 0.7:
             return rng.choice(["flag", "flag2"])
         if r < 0.8:
@@ -226,25 +280,28 @@ def check_same(ctx, rec, al, sql, kind):
 @pytest.mark.parametrize("n", SIZES)
 def test_fuzz_filter_vs_oracle(ctx, n):
     rng = np.random.default_rng(1000 + n)
-    rec = make_batch(n, n)
-    al = empty_aliases(rec)
     outcomes = {"ok": 0, "error": 0, "unsupported": 0}
-    for _ in range(12):
-        outcomes[check_same(ctx, rec, al, random_predicate(rng, 2), "filter")] += 1
-    # "error" outcomes are checked too (same status on both sides); tiny batches hit data-dependent errors often
-    assert outcomes["ok"] >= 3 and outcomes["unsupported"] <= 2, outcomes
+    for tame in (True, False):   # tame values: the cases compare VALUES; full-range values: boundary values and error statuses
+        rec = make_batch(n, n, tame=tame)
+        al = empty_aliases(rec)
+        for _ in range(12 if tame else 6):
+            outcomes[check_same(ctx, rec, al, random_predicate(rng, 2), "filter")] += 1
+    # "error" outcomes are checked too (same status on both sides), but a fuzz that mostly compares statuses proves little:
+    # at least 10 of the 18 cases must have compared values
+    assert outcomes["ok"] >= 10 and outcomes["unsupported"] <= 2, outcomes
 
 
 @pytest.mark.parametrize("n", [1, 65, 2049, 20_000])
 def test_fuzz_compute_value_vs_oracle(ctx, n):
     rng = np.random.default_rng(77 + n)
-    rec = make_batch(n, 5 * n + 1)
-    al = empty_aliases(rec)
     outcomes = {"ok": 0, "error": 0, "unsupported": 0}
-    for _ in range(25):
-        sql = random_numeric(rng, 3) if rng.random() < 0.6 else random_predicate(rng, 2)
-        outcomes[check_same(ctx, rec, al, sql, "value")] += 1
-    assert outcomes["ok"] >= 5 and outcomes["unsupported"] <= 3, outcomes
+    for tame in (True, False):
+        rec = make_batch(n, 5 * n + 1, tame=tame)
+        al = empty_aliases(rec)
+        for _ in range(25 if tame else 10):
+            sql = random_numeric(rng, 3) if rng.random() < 0.6 else random_predicate(rng, 2)
+            outcomes[check_same(ctx, rec, al, sql, "value")] += 1
+    assert outcomes["ok"] >= 20 and outcomes["unsupported"] <= 3, outcomes
 
 
 @pytest.mark.parametrize("split", [False, True])
