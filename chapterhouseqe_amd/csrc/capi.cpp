@@ -112,8 +112,13 @@ void export_group(GroupSliced&& g, int device_type, ArrowDeviceArray* outs, Arro
   blk->child_arrays.resize(nb * C); blk->child_ptrs.resize(nb * C); blk->bufs.assign(nb * C * 3, nullptr);
   blk->parent_bufs.assign(nb, nullptr); blk->child_schemas.resize(nb * C); blk->schild_ptrs.resize(nb * C);
   blk->live.store((int64_t)(nb * (2 + 2 * C)));
-  std::vector<const uint8_t*> vbase(C), dbase(C);
-  for (size_t i = 0; i < C; ++i) { vbase[i] = (const uint8_t*)g.values[i]->ptr; dbase[i] = g.data[i] ? (const uint8_t*)g.data[i]->ptr : nullptr; }
+  std::vector<const uint8_t*> vbase(C), dbase(C), nbase(C);
+  for (size_t i = 0; i < C; ++i) {
+    vbase[i] = (const uint8_t*)g.values[i]->ptr; dbase[i] = g.data[i] ? (const uint8_t*)g.data[i]->ptr : nullptr;
+    nbase[i] = (i < g.validity.size() && g.validity[i]) ? (const uint8_t*)g.validity[i]->ptr : nullptr;
+    if (nbase[i]) blk->buffers.push_back(g.validity[i]);
+  }
+  const bool host_out = device_type != ARROW_DEVICE_ROCM;
   pool_ranges(nb, 1024, [&](size_t b0, size_t b1) {
     for (size_t b = b0; b < b1; ++b) {
       const int64_t begin = b ? g.ends[b - 1] : 0, rows = g.ends[b] - begin;
@@ -123,9 +128,21 @@ void export_group(GroupSliced&& g, int device_type, ArrowDeviceArray* outs, Arro
         const void** cb = &blk->bufs[(b * C + i) * 3];
         memset(&ca, 0, sizeof ca);
         cb[0] = nullptr;
+        ca.null_count = 0;
         if (pc.type == T_UTF8) { cb[1] = vbase[i]; cb[2] = dbase[i]; ca.offset = begin; ca.n_buffers = 3; }   // a slice of the joined column
+        else if (pc.type == T_BOOL || nbase[i]) { cb[1] = vbase[i]; ca.offset = begin; ca.n_buffers = 2; }    // (one Arrow offset serves values and validity)
         else { cb[1] = vbase[i] + begin * pc.width; ca.offset = 0; ca.n_buffers = 2; }
-        ca.length = rows; ca.null_count = 0; ca.buffers = cb; ca.release = group_release_child_array; ca.private_data = blk;
+        if (nbase[i]) {   // nulls of the slice: unknown on the device (-1), counted for a host result; an all-valid slice drops the bitmap
+          cb[0] = nbase[i];
+          if (!host_out) ca.null_count = -1;
+          else {
+            int64_t nulls = 0;
+            for (int64_t r = begin; r < begin + rows; ++r) nulls += !((nbase[i][r >> 3] >> (r & 7)) & 1);
+            ca.null_count = nulls;
+            if (nulls == 0) cb[0] = nullptr;
+          }
+        }
+        ca.length = rows; ca.buffers = cb; ca.release = group_release_child_array; ca.private_data = blk;
         blk->child_ptrs[b * C + i] = &ca;
         ArrowSchema& cs = blk->child_schemas[b * C + i];
         memset(&cs, 0, sizeof cs);
@@ -148,18 +165,61 @@ void export_group(GroupSliced&& g, int device_type, ArrowDeviceArray* outs, Arro
   });
 }
 
-// import of a group: the batches and, in the same pass, their GroupLite
-void import_group(int n_records, const ArrowDeviceArray* const* recs, const ArrowSchema* schema, int device, std::vector<Batch>& in, GroupLite& lite) {
-  in.resize((size_t)n_records);
+// Import of a group.  Batch 0 is imported in full.  A DEVICE-resident group then only gathers its GroupLite -- the checks of
+// import_batch on every record, but no Batch objects: the one-launch path works from the flat arrays, and building and
+// freeing 12 500 Batch objects cost ~0.6 ms of a 2.5 ms call; `gi.materialise` imports them when another path needs them.
+// Host groups (staged and packed from the batches themselves) are imported in full, with their GroupLite on the side.
+void lite_from_arrow(const ArrowDeviceArray* rec, const ArrowSchema* schema, const Batch& first, int device, GroupLite& lite, size_t b) {
+  const ArrowArray& a = rec->array;
+  const size_t nc = lite.ncols;
+  uint8_t f = 0;
+  if (a.offset != 0 || a.n_children != schema->n_children || (size_t)a.n_children != nc || rec->device_type != ARROW_DEVICE_ROCM || rec->sync_event) {
+    lite.flags[b] = GroupLite::GL_SCHEMA_DIFFERS;   // (anything unusual: the full import decides -- and reports)
+    return;
+  }
+  const int64_t rows = a.length;
+  lite.rows[b] = rows;
+  if ((int)rec->device_id == device) f |= GroupLite::GL_ON_DEVICE;
+  if (rows < 2) f |= GroupLite::GL_SHORT;
+  for (size_t i = 0; i < nc; ++i) {
+    const ArrowArray* ca = a.children[i];
+    const Column& c0 = first.cols[i];
+    if (!ca || ca->length < rows || ca->offset < 0 || ca->n_buffers < 2 || !ca->buffers || !ca->buffers[1] ||
+        (ca->null_count > 0 && !ca->buffers[0])) { f |= GroupLite::GL_SCHEMA_DIFFERS; continue; }
+    const uint8_t* validity = (const uint8_t*)ca->buffers[0];
+    const uint8_t* values = (const uint8_t*)ca->buffers[1];
+    if (validity && ca->null_count != 0) f |= GroupLite::GL_NULLS;
+    if (c0.type == T_UTF8) {
+      const uint8_t* data = ca->n_buffers > 2 ? (const uint8_t*)ca->buffers[2] : nullptr;
+      if (!data) f |= GroupLite::GL_NO_UTF8_DATA;
+      lite.values0[b * nc + i] = values + 4 * ca->offset; lite.data[b * nc + i] = data;
+    } else if (c0.type == T_BOOL) lite.values0[b * nc + i] = values;
+    else lite.values0[b * nc + i] = values + (int64_t)c0.width * ca->offset;
+  }
+  lite.flags[b] = f;
+}
+
+void import_group(int n_records, const ArrowDeviceArray* const* recs, const ArrowSchema* schema, int device, std::vector<Batch>& in,
+                  GroupLite& lite, GroupInput& gi) {
+  in.resize(1);
   in[0] = import_batch(recs[0], schema);
   lite.resize((size_t)n_records, in[0].cols.size());
   lite.set(0, in[0], in[0], device);
+  gi.batches = &in; gi.lite = &lite;
+  auto import_rest = [n_records, recs, schema, &in]() {
+    if ((int)in.size() == n_records) return;
+    in.resize((size_t)n_records);
+    if (n_records > 1) for_each_parallel(n_records - 1, [&](int k) { in[(size_t)k + 1] = import_batch(recs[(size_t)k + 1], schema); });
+  };
+  if (in[0].on_device && n_records > 1) {
+    const Batch& first = in[0];
+    for_each_parallel(n_records - 1, [&](int k) { lite_from_arrow(recs[(size_t)k + 1], schema, first, device, lite, (size_t)k + 1); });
+    gi.materialise = import_rest;
+    return;
+  }
+  import_rest();
   const Batch& first = in[0];
-  if (n_records > 1) for_each_parallel(n_records - 1, [&](int k) {
-    const size_t i = (size_t)k + 1;
-    in[i] = import_batch(recs[i], schema);
-    lite.set(i, in[i], first, device);
-  });
+  if (n_records > 1) for_each_parallel(n_records - 1, [&](int k) { lite.set((size_t)k + 1, in[(size_t)k + 1], first, device); });
 }
 
 }  // namespace
@@ -238,6 +298,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "time_kernels") ctx->c.opt_time_kernels = value != 0;
     else if (k == "fold_utf8") ctx->c.opt_fold_utf8 = value != 0;
     else if (k == "group_fold") ctx->c.opt_group_fold = value != 0;
+    else if (k == "group_bits") ctx->c.opt_group_bits = value != 0;
     else if (k == "large_host") ctx->c.opt_large_host = value != 0;
     else if (k == "large_host_chunk") { if (value < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "large_host_chunk must not be negative"}; ctx->c.opt_large_host_chunk = value; }
     else if (k == "large_host_rows") { if (value < 1) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "large_host_rows must be positive"}; ctx->c.opt_large_host_rows = value; }
@@ -346,11 +407,12 @@ chq_status chq_filter_records(chq_ctx* ctx, int n_records, const ArrowDeviceArra
     PhaseTimer pt("chq_filter_records");
     std::vector<Batch> in;
     GroupLite lite;
+    GroupInput gi;
     for (int i = 0; i < n_records; ++i) require(recs[i], "record");
-    import_group(n_records, recs, schema, ctx->c.device, in, lite);
+    import_group(n_records, recs, schema, ctx->c.device, in, lite, gi);
     pt.mark("import");
     GroupSliced sliced;
-    std::vector<Batch> res = filter_records(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &lite, &sliced);
+    std::vector<Batch> res = filter_records(ctx->c, gi, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &sliced);
     pt.mark("filter");
     if (sliced.filled) { export_group(std::move(sliced), out_device, outs, out_schemas); pt.mark("export"); return; }
     try {
@@ -380,11 +442,12 @@ chq_status chq_filter_records_coalesced(chq_ctx* ctx, int n_records, const Arrow
     PhaseTimer pt("chq_filter_records_coalesced");
     std::vector<Batch> in;
     GroupLite lite;
+    GroupInput gi;
     for (int i = 0; i < n_records; ++i) require(recs[i], "record");
-    import_group(n_records, recs, schema, ctx->c.device, in, lite);
+    import_group(n_records, recs, schema, ctx->c.device, in, lite, gi);
     pt.mark("import");
     std::vector<int64_t> rows;
-    Batch res = filter_records_coalesced(ctx->c, in, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &rows, &lite);
+    Batch res = filter_records_coalesced(ctx->c, gi, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &rows);
     pt.mark("filter");
     if (rows_per_record) for (int i = 0; i < n_records; ++i) rows_per_record[i] = rows[(size_t)i];
     export_batch(std::move(res), out_device, out, out_schema);

@@ -177,6 +177,12 @@ struct FilterParams {
   int32_t group_wpb;
   int32_t group_nb;
   u64* group_batch_end;
+  // Wave-packed groups whose batches carry validity bitmaps or Boolean columns (round 3): word group_bits_at + k of a
+  // batch's table row is the bitmap of program column-ref k (its validity, or for a Boolean column its values; 0 = no
+  // bitmap: every row valid) and word group_bits_at + n_refs + k the bit position of the batch's row 0 in it.  0 = none.
+  // sel_mask / grp_base of such a launch are indexed by wave slot: entry (tile * waves per tile + wave) * R + j.
+  int32_t group_bits_at;
+  int32_t pad2;
   Utf8Fold utf8[MAX_FOLD_UTF8];
   ProgramBlock pb;
   OutCol outs[MAX_OUT];
@@ -227,6 +233,21 @@ struct BitCompactParams {   // bool values / validity bitmaps
   const void* in_bits; int64_t in_bit_offset;
   uint32_t* out_bits;       // zero-initialised; bit k = k-th selected row
   u64* zero_count;     // optional: counts selected rows whose bit is 0 (null count)
+};
+
+// bit_compact_group_kernel: bit_compact_kernel for a wave-packed group -- out bit k = bit of the k-th selected row of the
+// GROUP; chunk c (one wave slot of the main kernel: 64 R rows of one batch) reads batch c / wpb's bitmap.
+struct BitCompactGroupParams {
+  const u64* sel_mask;       // indexed by wave slot (see FilterParams::group_bits_at)
+  const u64* grp_base;
+  const u64* table;          // the main launch's group table
+  int64_t stride;            // words per batch
+  int32_t word_ptr, word_off;   // words of a table row: the bitmap (0: all ones) and the bit position of row 0
+  int32_t wpb, nb;
+  int32_t rows_per_wave;     // 64 R of the main kernel's tile kind
+  int32_t pad;
+  uint32_t* out_bits;        // zero-initialised
+  u64* zero_count;
 };
 
 struct SplitBoundsParams {   // split_bounds_kernel: out[i] = number of selected rows before input row starts[i]

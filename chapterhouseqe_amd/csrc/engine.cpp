@@ -1725,7 +1725,7 @@ struct Utf8Sizes {
 };
 Utf8Sizes device_utf8_bytes_issue(Context& ctx, const std::vector<Batch>& recs, const GroupLite* lite, const std::vector<int>& utf8_cols) {
   Utf8Sizes z;
-  z.cols = utf8_cols; z.nb = recs.size();
+  z.cols = utf8_cols; z.nb = lite ? lite->rows.size() : recs.size();
   const size_t nb = z.nb, nu = utf8_cols.size();
   if (nu == 0) return z;
   const size_t words = (nb + 1) + nu * nb;                 // row_at, then one pointer table per column
@@ -1777,20 +1777,20 @@ namespace {
 // `co` != nullptr asks for ONE output batch (all surviving rows, input order) + rows per input batch; the one-launch
 // path fills it directly and sets co->done, every other path returns per-batch outputs for the caller to join
 struct Coalesced { Batch out; std::vector<int64_t> rows; bool done = false; };
-std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                       const Expr& expr, bool out_on_device, Coalesced* co, const GroupLite* lite, GroupSliced* sliced);
+std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const chq_table_aliases* aliases,
+                                       const Expr& expr, bool out_on_device, Coalesced* co, GroupSliced* sliced);
 }  // namespace
 
-std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                  const Expr& expr, bool out_on_device, const GroupLite* lite, GroupSliced* sliced) {
-  return filter_records_impl(ctx, recs, aliases, expr, out_on_device, nullptr, lite, sliced);
+std::vector<Batch> filter_records(Context& ctx, const GroupInput& in, const chq_table_aliases* aliases,
+                                  const Expr& expr, bool out_on_device, GroupSliced* sliced) {
+  return filter_records_impl(ctx, in, aliases, expr, out_on_device, nullptr, sliced);
 }
 
-Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record, const GroupLite* lite) {
-  if (recs.empty()) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "no record batches to coalesce"};
+Batch filter_records_coalesced(Context& ctx, const GroupInput& in, const chq_table_aliases* aliases,
+                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record) {
+  if (!in.batches || in.batches->empty()) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "no record batches to coalesce"};
   Coalesced co;
-  std::vector<Batch> outs = filter_records_impl(ctx, recs, aliases, expr, out_on_device, &co, lite, nullptr);
+  std::vector<Batch> outs = filter_records_impl(ctx, in, aliases, expr, out_on_device, &co, nullptr);
   if (!co.done) {   // join the per-batch results on the host (general column kinds), then move them where they are wanted
     const chq_call_stats st = ctx.stats;
     std::vector<Batch> host;
@@ -1805,11 +1805,16 @@ Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, con
 }
 
 namespace {
-std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                       const Expr& expr, bool out_on_device, Coalesced* co, const GroupLite* lite, GroupSliced* sliced) {
-  const size_t nb = recs.size();
-  if (lite && (lite->rows.size() != nb || nb == 0 || lite->ncols != recs[0].cols.size())) lite = nullptr;
+std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const chq_table_aliases* aliases,
+                                       const Expr& expr, bool out_on_device, Coalesced* co, GroupSliced* sliced) {
+  const std::vector<Batch>& recs = *gi.batches;   // (batch 0 is always there; the others after need_batches() when `lite` is set)
+  const GroupLite* lite = gi.lite;
+  if (lite && (lite->rows.empty() || recs.empty() || lite->ncols != recs[0].cols.size())) lite = nullptr;
+  auto need_batches = [&]() { if (gi.materialise) gi.materialise(); };
+  if (!lite) need_batches();
+  const size_t nb = lite ? lite->rows.size() : recs.size();
   auto per_batch_loop = [&]() {
+    need_batches();
     std::vector<Batch> outs;
     chq_call_stats acc{};
     for (const Batch& r : recs) {
@@ -1827,6 +1832,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   // big batch (every column kind is supported there), copy the result back once and slice it per input batch at the
   // positions the device reports (split_bounds_kernel).  Chunks keep every Utf8 column below 1 GiB of bytes.
   auto host_concat_path = [&]() -> std::vector<Batch> {
+    need_batches();
     const size_t nc = recs[0].cols.size();
     std::vector<size_t> cuts{0};
     {
@@ -1885,6 +1891,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   // ordinary kernels, cut at the batch boundaries the device reports (split_bounds_kernel).  Every output batch is a
   // slice (Arrow offset) of the shared result buffers; chunks keep every Utf8 column below the int32 offset range.
   auto device_concat_path = [&]() -> std::vector<Batch> {
+    need_batches();
     const size_t nc = recs[0].cols.size();
     std::vector<int> utf8_cols;
     for (size_t i = 0; i < nc; ++i) if (recs[0].cols[i].type == T_UTF8) utf8_cols.push_back((int)i);
@@ -1956,7 +1963,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   // `foldable`: device-resident, non-null, fixed-width or Utf8 columns -- short-string Utf8 columns can then be filtered
   // straight out of the batches by the one-launch path (their offsets and bytes per batch ride in the group table)
   bool foldable = (int)ncols <= MAX_OUT && ctx.opt_fold_utf8 && ctx.opt_group_fold;
-  bool has_bool = false, has_utf8 = false;
+  bool has_bool = false, has_utf8 = false, need_bits = false;
   for (size_t i = 0; i < ncols; ++i) { has_bool |= recs[0].cols[i].type == T_BOOL; has_utf8 |= recs[0].cols[i].type == T_UTF8; }
   if (lite && recs[0].on_device) {
     // device-resident group: the facts were gathered per batch at import (GroupLite) -- one pass over nb bytes
@@ -1964,10 +1971,14 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     for (uint8_t f : lite->flags) { any |= f; all &= f; }
     if (any & (GroupLite::GL_SHORT | GroupLite::GL_SCHEMA_DIFFERS)) { if (any & GroupLite::GL_SHORT) return per_batch_loop(); same_schema = false; }
     all_host = false;
-    const bool nulls = any & GroupLite::GL_NULLS;
-    plain = plain && !has_bool && !has_utf8 && !nulls;
-    foldable = foldable && (all & GroupLite::GL_ON_DEVICE) && !has_bool && !nulls && !(any & GroupLite::GL_NO_UTF8_DATA);
-  } else
+    // validity bitmaps and Boolean columns ride along in the one-launch path when the group is wave-packed (decided below):
+    // their bitmaps are compacted by bit_compact_group_kernel behind the main kernel
+    need_bits = has_bool || (any & GroupLite::GL_NULLS);
+    const bool all_dev = all & GroupLite::GL_ON_DEVICE;
+    plain = plain && !has_utf8 && (!need_bits || (all_dev && ctx.opt_group_bits));
+    foldable = foldable && all_dev && !(any & GroupLite::GL_NO_UTF8_DATA) && (!need_bits || ctx.opt_group_bits);
+  } else {
+  need_batches();
   for (const Batch& r : recs) {
     if (r.cols.size() != ncols || r.nrows < 2) return per_batch_loop();
     all_host &= !r.on_device;
@@ -1979,6 +1990,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
                count_nulls_host(c.validity, c.offset, c.length) != 0));
       foldable &= c.type != T_BOOL && !(c.validity && c.null_count != 0) && (c.type != T_UTF8 || c.data != nullptr);
     }
+  }
   }
   if (!same_schema) return per_batch_loop();
   std::vector<int> fold_utf8;                          // the Utf8 columns of a foldable group
@@ -2042,7 +2054,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     for (int64_t r : lite->rows) { total_rows += r; max_rows = std::max(max_rows, r); }
     bool all_dev = true;
     for (uint8_t f : lite->flags) all_dev &= (f & GroupLite::GL_ON_DEVICE) != 0;
-    if (!all_dev || has_bool || (has_utf8 && !fold) || !(plain || fold)) return per_batch_loop();
+    if (!all_dev || (has_utf8 && !fold) || !(plain || fold)) return per_batch_loop();
   } else
   for (const Batch& r : recs) {
     if (r.cols.size() != ncols || r.nrows < 2 || r.on_device == host_in) return per_batch_loop();
@@ -2137,13 +2149,40 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   ensure_scratch(ctx, ntiles);
   Scratch* ds = dev_scratch(ctx);
 
+  // ---- bitmaps (validity of any column, values of Boolean columns): wave-packed groups only --------------------------
+  // `proto` = batch 0 with every column that has nulls in ANY batch marked nullable: the program is lowered / pre-decoded
+  // against it (a ref that may be null must take the generic interpreter even if batch 0 happens to be null-free)
+  Batch proto = recs[0];
+  std::vector<char> col_nulls(ncols, 0);
+  struct BitCol { int col; bool validity; size_t word; };   // word: index of {bitmap, bit offset} in a batch's table row
+  std::vector<BitCol> bit_cols;
+  if (need_bits) {
+    if (wpb == 0) return other_path();   // ragged group: joined on the device
+    need_batches();   // (the bitmaps' addresses and offsets are read from the batches)
+    pool_ranges(nb, 2048, [&](size_t b0, size_t b1) {
+      for (size_t b = b0; b < b1; ++b) {
+        if (!(lite->flags[b] & GroupLite::GL_NULLS)) continue;
+        for (size_t i = 0; i < ncols; ++i) if (recs[b].cols[i].validity && recs[b].cols[i].null_count != 0) col_nulls[i] = 1;
+      }
+    });
+    for (size_t i = 0; i < ncols; ++i) {
+      if (col_nulls[i]) { proto.cols[i].validity = (const uint8_t*)proto.cols[i].values; proto.cols[i].null_count = 1; }   // (never read: a marker)
+      else { proto.cols[i].validity = nullptr; proto.cols[i].null_count = 0; }
+      if (recs[0].cols[i].type == T_BOOL) bit_cols.push_back(BitCol{(int)i, false, 0});
+      if (col_nulls[i]) bit_cols.push_back(BitCol{(int)i, true, 0});
+    }
+    if (bit_cols.size() > 16) return other_path();   // (one null counter each in the scratch header)
+  }
+
   // column order of the launch: the stashed predicate column goes last (see filter_record)
   std::vector<int> launch_cols;
-  for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type != T_UTF8) launch_cols.push_back((int)i);
+  for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type != T_UTF8 && recs[0].cols[i].type != T_BOOL) launch_cols.push_back((int)i);
   FilterParams p{};
-  pick_stash(p, ctx, lw, recs[0].cols, launch_cols, tile_kind);
+  pick_stash(p, ctx, lw, proto.cols, launch_cols, tile_kind);
   const size_t nrefs = lw.refs.size(), nout = launch_cols.size(), nu = fold ? fold_utf8.size() : 0;
-  const size_t stride = (wpb > 0 ? 1 : 2) + nrefs + nout + 2 * nu;   // per Utf8 column: the batch's offsets and bytes
+  size_t stride = (wpb > 0 ? 1 : 2) + nrefs + nout + 2 * nu;   // per Utf8 column: the batch's offsets and bytes
+  const size_t bits_at = need_bits ? stride : 0;               // validity bitmap + bit offset of every program ref
+  if (need_bits) { stride += 2 * nrefs; for (BitCol& q : bit_cols) { q.word = stride; stride += 2; } }
   if (fold && tile_kind == 2) return other_path();
 
   // ---- table (+ index of every batch's last tile in tile mode): built in pinned memory, one upload ---------------
@@ -2166,6 +2205,16 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
         for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][lw.refs[k]];
         for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
         for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = utf8_data(b, k); }
+        if (need_bits) {
+          const Batch& rb = recs[b];
+          auto vbits = [&](size_t i) -> u64 { const Column& c = rb.cols[i]; return (c.validity && c.null_count != 0) ? (u64)(uintptr_t)c.validity : 0; };
+          for (size_t k = 0; k < nrefs; ++k) *w++ = vbits((size_t)lw.refs[k]);
+          for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)rb.cols[(size_t)lw.refs[k]].offset;
+          for (const BitCol& q : bit_cols) {
+            *w++ = q.validity ? vbits((size_t)q.col) : (u64)(uintptr_t)rb.cols[(size_t)q.col].values;
+            *w++ = (u64)rb.cols[(size_t)q.col].offset;
+          }
+        }
         continue;
       }
       for (int64_t r0 = 0; r0 < rows; r0 += tile_rows, ++tile) {
@@ -2187,9 +2236,16 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   // ---- dense outputs ---------------------------------------------------------------------------------------
   std::vector<BufferPtr> dense(ncols), dense_data(ncols), fold_status;
   for (size_t i = 0; i < ncols; ++i) {
-    if (recs[0].cols[i].type == T_UTF8) continue;
+    if (recs[0].cols[i].type == T_UTF8 || recs[0].cols[i].type == T_BOOL) continue;
     dense[i] = make_device_buffer((size_t)(total_rows * recs[0].cols[i].width) + 16, ctx.device);
     ctx.stats.bytes_read_alg += total_rows * recs[0].cols[i].width;
+  }
+  BufferPtr g_sel, g_base;
+  const int64_t nslots = need_bits ? ntiles * kWavesPerTile[tile_kind] * (kWaveRows[tile_kind] / 64) : 0;
+  if (need_bits) {
+    g_sel = make_device_buffer((size_t)(nslots + 8) * 8, ctx.device);
+    g_base = make_device_buffer((size_t)(nslots + 8) * 8, ctx.device);
+    p.sel_mask = (u64*)g_sel->ptr; p.grp_base = (u64*)g_base->ptr; p.group_bits_at = (int32_t)bits_at;
   }
   for (size_t k = 0; k < nu; ++k) {   // Utf8 columns: joined offsets (from 0) and bytes, capacity = the input bytes
     const size_t i = (size_t)fold_utf8[k];
@@ -2208,7 +2264,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
   p.nrows = ntiles * tile_rows;   // only locates the last tile; per-tile row ranges come from the table
   p.status = dev_status(ctx);
   p.ticket = &ds->ticket; p.total = &ds->total; p.err = &ds->err;
-  fill_refs(p.pb, lw, recs[0], {});
+  fill_refs(p.pb, lw, proto, {});
   for (size_t k = 0; k < nout; ++k) {
     p.outs[k].in = nullptr; p.outs[k].out = dense[launch_cols[k]]->ptr; p.outs[k].width = (uint32_t)recs[0].cols[launch_cols[k]].width;
   }
@@ -2230,6 +2286,19 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     check_hip(launch_gather_status(gp, ctx.stream), "launch gather_status_kernel");
     ctx.stats.launches = 2;
   }
+  std::vector<BufferPtr> bit_out(bit_cols.size());
+  const size_t bit_bytes = (size_t)(total_rows + 31) / 32 * 4 + 16;
+  for (size_t q = 0; q < bit_cols.size(); ++q) {   // one joined bitmap per Boolean column / per column with nulls
+    bit_out[q] = make_device_buffer(bit_bytes, ctx.device);
+    check_hip(hipMemsetAsync(bit_out[q]->ptr, 0, bit_bytes, ctx.stream), "memset bits");
+    BitCompactGroupParams bp{};
+    bp.sel_mask = (const u64*)g_sel->ptr; bp.grp_base = (const u64*)g_base->ptr; bp.table = (const u64*)d_tbl->ptr; bp.stride = (int64_t)stride;
+    bp.word_ptr = (int32_t)bit_cols[q].word; bp.word_off = (int32_t)bit_cols[q].word + 1; bp.wpb = (int32_t)wpb; bp.nb = (int32_t)nb;
+    bp.rows_per_wave = (int32_t)kWaveRows[tile_kind]; bp.out_bits = (uint32_t*)bit_out[q]->ptr;
+    bp.zero_count = bit_cols[q].validity ? &ds->counters[q] : nullptr;
+    check_hip(launch_bit_compact_group(bp, (int)std::min<int64_t>((wpb * (int64_t)nb + 3) / 4, (int64_t)ctx.num_cus * 8), ctx.stream), "launch bit_compact_group_kernel");
+    ++ctx.stats.launches;
+  }
   Scratch* hs = (Scratch*)ctx.pinned;
   check_hip(hipMemcpyAsync(hs, ds, sizeof(Scratch), hipMemcpyDeviceToHost, ctx.stream), "read back");
   check_hip(hipMemcpyAsync(h_cnt, d_cnt, bytes_cnt, hipMemcpyDeviceToHost, ctx.stream), "read back batch prefixes");
@@ -2246,35 +2315,41 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     out_bytes[(size_t)fold_utf8[k]] = (int64_t)hs->fold_bytes[k];
     ctx.stats.bytes_read_alg += (int64_t)hs->fold_bytes[k]; ctx.stats.bytes_written_alg += (total + 1) * 4 + (int64_t)hs->fold_bytes[k];
   }
-  for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type != T_UTF8) ctx.stats.bytes_written_alg += total * recs[0].cols[i].width;
+  for (size_t i = 0; i < ncols; ++i) if (recs[0].cols[i].type != T_UTF8 && recs[0].cols[i].type != T_BOOL) ctx.stats.bytes_written_alg += total * recs[0].cols[i].width;
 
-  // ---- slice the dense outputs ---------------------------------------------------------------------------------
-  std::vector<BufferPtr> host_dense, host_data(ncols);
-  if (!out_on_device) {
+  // ---- the joined output columns: values (a Boolean column: its joined bitmap), Utf8 bytes, validity --------------------
+  struct JoinedCol { BufferPtr values, data, validity; int64_t nulls = 0; };
+  std::vector<JoinedCol> joined(ncols);
+  for (size_t i = 0; i < ncols; ++i) { joined[i].values = dense[i]; joined[i].data = dense_data[i]; }
+  for (size_t q = 0; q < bit_cols.size(); ++q) {
+    JoinedCol& jc = joined[(size_t)bit_cols[q].col];
+    if (!bit_cols[q].validity) jc.values = bit_out[q];
+    else if (hs->counters[q] != 0) { jc.validity = bit_out[q]; jc.nulls = (int64_t)hs->counters[q]; }   // (arrow drops an all-valid null buffer)
+  }
+  if (!out_on_device) {   // host result: every joined buffer comes down once
     for (size_t i = 0; i < ncols; ++i) {
-      const bool u8 = recs[0].cols[i].type == T_UTF8;
-      const size_t bytes = u8 ? (size_t)(total + 1) * 4 : (size_t)(total * recs[0].cols[i].width);
-      auto hb = make_host_buffer(bytes + 16);
-      if (bytes) check_hip(hipMemcpyAsync(hb->ptr, dense[i]->ptr, bytes, hipMemcpyDeviceToHost, ctx.stream), "download dense column");
-      host_dense.push_back(hb);
-      if (u8) {
-        host_data[i] = make_host_buffer((size_t)out_bytes[i] + 16);
-        if (out_bytes[i]) check_hip(hipMemcpyAsync(host_data[i]->ptr, dense_data[i]->ptr, (size_t)out_bytes[i], hipMemcpyDeviceToHost, ctx.stream), "download string bytes");
-      }
+      const DType ty = recs[0].cols[i].type;
+      auto down = [&](BufferPtr& b, size_t bytes) {
+        if (!b) return;
+        auto hb = make_host_buffer(bytes + 16);
+        if (bytes) check_hip(hipMemcpyAsync(hb->ptr, b->ptr, bytes, hipMemcpyDeviceToHost, ctx.stream), "download joined column");
+        b = hb;
+      };
+      down(joined[i].values, ty == T_UTF8 ? (size_t)(total + 1) * 4 : ty == T_BOOL ? (size_t)(total + 7) / 8 : (size_t)(total * recs[0].cols[i].width));
+      down(joined[i].data, (size_t)out_bytes[i]);
+      down(joined[i].validity, (size_t)(total + 7) / 8);
     }
     check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   }
-  if (co) {   // the dense buffers ARE the coalesced batch
+  if (co) {   // the joined buffers ARE the coalesced batch
     co->out.on_device = out_on_device; co->out.device_id = out_on_device ? ctx.device : -1;
     co->out.nrows = total;
     for (size_t i = 0; i < ncols; ++i) {
       Column c = empty_like(recs[0].cols[i]);
-      const BufferPtr& buf = out_on_device ? dense[i] : host_dense[i];
-      c.values = (const uint8_t*)buf->ptr; c.length = total; c.owned.push_back(buf);
-      if (c.type == T_UTF8) {
-        const BufferPtr& db = out_on_device ? dense_data[i] : host_data[i];
-        c.data = (const uint8_t*)db->ptr; c.data_bytes = out_bytes[i]; c.owned.push_back(db);
-      }
+      const JoinedCol& jc = joined[i];
+      c.values = (const uint8_t*)jc.values->ptr; c.length = total; c.owned.push_back(jc.values);
+      if (c.type == T_UTF8) { c.data = (const uint8_t*)jc.data->ptr; c.data_bytes = out_bytes[i]; c.owned.push_back(jc.data); }
+      if (jc.validity) { c.validity = (const uint8_t*)jc.validity->ptr; c.null_count = jc.nulls; c.owned.push_back(jc.validity); }
       co->out.cols.push_back(std::move(c));
     }
     int64_t prev = 0;
@@ -2282,12 +2357,13 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     co->done = true;
     return {};
   }
-  if (sliced) {   // the caller cuts the dense buffers into Arrow structs itself (capi.cpp: one block for the whole group)
+  if (sliced) {   // the caller cuts the joined buffers into Arrow structs itself (capi.cpp: one block for the whole group)
     sliced->filled = true; sliced->on_device = out_on_device; sliced->device_id = out_on_device ? ctx.device : -1;
     for (size_t i = 0; i < ncols; ++i) {
       sliced->proto.push_back(empty_like(recs[0].cols[i]));
-      sliced->values.push_back(out_on_device ? dense[i] : host_dense[i]);
-      sliced->data.push_back(recs[0].cols[i].type == T_UTF8 ? (out_on_device ? dense_data[i] : host_data[i]) : BufferPtr());
+      sliced->values.push_back(joined[i].values);
+      sliced->data.push_back(joined[i].data);
+      sliced->validity.push_back(joined[i].validity);
     }
     sliced->ends.assign(h_cnt, h_cnt + nb);
     return {};
@@ -2300,15 +2376,20 @@ std::vector<Batch> filter_records_impl(Context& ctx, const std::vector<Batch>& r
     o.on_device = out_on_device; o.device_id = out_on_device ? ctx.device : -1;
     o.nrows = end - begin;
     for (size_t i = 0; i < ncols; ++i) {
-      Column c = empty_like(recs[b].cols[i]);
-      const BufferPtr& buf = out_on_device ? dense[i] : host_dense[i];
+      Column c = empty_like(recs[0].cols[i]);
+      const JoinedCol& jc = joined[i];
       c.length = o.nrows;
-      c.owned.push_back(buf);
-      if (c.type == T_UTF8) {   // a slice of the joined column: shared offsets and bytes, Arrow offset = first row
-        const BufferPtr& db = out_on_device ? dense_data[i] : host_data[i];
-        c.values = (const uint8_t*)buf->ptr; c.offset = begin;
-        c.data = (const uint8_t*)db->ptr; c.owned.push_back(db);
-      } else c.values = (const uint8_t*)buf->ptr + begin * c.width;
+      c.owned.push_back(jc.values);
+      if (c.type == T_UTF8 || c.type == T_BOOL || jc.validity) {
+        // a slice of the joined column: shared buffers, Arrow offset = first row (one offset serves values and validity)
+        c.values = (const uint8_t*)jc.values->ptr; c.offset = begin;
+        if (c.type == T_UTF8) { c.data = (const uint8_t*)jc.data->ptr; c.owned.push_back(jc.data); }
+        if (jc.validity) {
+          c.validity = (const uint8_t*)jc.validity->ptr; c.owned.push_back(jc.validity);
+          if (out_on_device) c.null_count = -1;   // unknown for the slice (Arrow C Data Interface: -1)
+          else { c.null_count = count_nulls_host(c.validity, c.offset, c.length); if (c.null_count == 0) c.validity = nullptr; }
+        }
+      } else c.values = (const uint8_t*)jc.values->ptr + begin * c.width;
       o.cols.push_back(std::move(c));
     }
     begin = end;

@@ -22,6 +22,7 @@ hipError_t launch_filter(const FilterParams& p, int tile_kind, bool partial, int
 hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, hipStream_t stream);
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
+hipError_t launch_bit_compact_group(const BitCompactGroupParams& p, int grid, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);
@@ -123,6 +124,7 @@ struct Context {
   int64_t opt_large_host = 1;       // host batches of opt_large_host_rows rows or more: chunked, uploads and downloads overlapped
   int64_t opt_large_host_rows = 8 << 20;
   int64_t opt_large_host_chunk = 0;  // rows per chunk (0: about 64 MB of input)
+  int64_t opt_group_bits = 1;       // wave-packed device groups with validity bitmaps / Boolean columns take the one-launch path (0: joined first)
   int64_t opt_group_fold = 1;       // device-resident groups with short-string Utf8 columns: filtered straight out of the batches (0: joined first)
   int64_t opt_fold_utf8 = 1;        // short-string Utf8 columns are filtered inside filter_fused_kernel (0: always the separate Utf8 pass)
   int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots
@@ -210,16 +212,26 @@ struct GroupSliced {
   bool filled = false, on_device = false;
   int device_id = -1;
   std::vector<Column> proto;               // per column: name / format / type / width / nullable flag
-  std::vector<BufferPtr> values, data;     // per column: values (Utf8: joined offsets), Utf8 bytes
+  std::vector<BufferPtr> values, data, validity;   // per column: values (Utf8: joined offsets; Boolean: joined bitmap), Utf8 bytes, joined validity bitmap or null
   std::vector<int64_t> ends;               // [nb] exclusive end row of every batch in the dense output
 };
-// one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says.  `lite`
-// (optional): the batches' GroupLite; `sliced` (optional): filled instead of the returned vector when the one-launch path ran
-std::vector<Batch> filter_records(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                                  const Expr& expr, bool out_on_device, const GroupLite* lite = nullptr, GroupSliced* sliced = nullptr);
+// The batches of a group call.  `batches` always holds batch 0; with `lite` the others may be missing until `materialise`
+// (imports every batch; idempotent) has run -- the one-launch path of a device-resident group works from `lite` alone, and
+// 10^4 Batch objects it never looks at cost more to build and free than the rest of the call's host work.
+struct GroupInput {
+  std::vector<Batch>* batches = nullptr;
+  const GroupLite* lite = nullptr;
+  std::function<void()> materialise;
+};
+// one launch for a group of same-schema batches (host or device resident); outputs where `out_on_device` says.
+// `sliced` (optional): filled instead of the returned vector when the one-launch path ran
+std::vector<Batch> filter_records(Context& ctx, const GroupInput& in, const chq_table_aliases* aliases,
+                                  const Expr& expr, bool out_on_device, GroupSliced* sliced = nullptr);
 // the same, but ONE output batch holding every surviving row in input order (+ surviving rows per input batch)
-Batch filter_records_coalesced(Context& ctx, const std::vector<Batch>& recs, const chq_table_aliases* aliases,
-                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record, const GroupLite* lite = nullptr);
+Batch filter_records_coalesced(Context& ctx, const GroupInput& in, const chq_table_aliases* aliases,
+                               const Expr& expr, bool out_on_device, std::vector<int64_t>* rows_per_record);
+// (convenience for callers that hold complete batches)
+inline GroupInput group_of(std::vector<Batch>& batches) { GroupInput g; g.batches = &batches; return g; }
 Batch project_record(Context& ctx, const std::vector<chq_select_item>& fields, const Batch& rec_dev,
                      const std::vector<PlanColumn>& pcols);
 // filter_record + project_record in one kernel pass; false = outside its scope (or an error was flagged): run the two steps

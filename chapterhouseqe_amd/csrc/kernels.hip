@@ -273,6 +273,8 @@ struct Interp {
   int stash_ref[NSA];
   int n_stash = 0;
   const u64* ptr_row = nullptr;   // batch-group launch: value pointer of column-ref k is ptr_row[k] (PARTIAL only)
+  const u64* ptr_bits = nullptr;  // ... and, when the group carries bitmaps: ptr_bits[k] = validity bitmap of column-ref k in this
+  int n_refs_bits = 0;            // wave's batch (0: none), ptr_bits[n_refs_bits + k] = bit position of the batch's row 0 in its bitmaps
 
   __device__ __forceinline__ void set_rows(int64_t tile_start, int64_t nrows_, int lane_, int wv_) {
     lane = lane_; wv = wv_; nrows = nrows_;
@@ -385,6 +387,19 @@ struct Interp {
       else fetch_values<true>(c, c.values, l, h);
     } else {
       const void* vals = ptr_row ? (const void*)ptr_row[ref_idx] : c.values;
+      if (ptr_bits) {   // batch-group launch with bitmaps: this wave's batch has its own (see FilterParams::group_bits_at)
+        const int64_t bitoff = (int64_t)ptr_bits[n_refs_bits + ref_idx];
+#pragma unroll
+        for (int j = 0; j < R; ++j) l[j] = 0;
+#pragma unroll
+        for (int j = 0; j < RH; ++j) h[j] = 0;
+        if (c.type == T_BOOL) { if (nact > 0) b = fetch_flags(vals, bitoff); }   // (a Boolean column's value pointer is its bitmap)
+        else if (nact == 64 * R) fetch_values<true>(c, vals, l, h);
+        else if (nact > 0) fetch_values<false>(c, vals, l, h);
+        const void* vb = (const void*)ptr_bits[ref_idx];
+        v = (vb && nact > 0) ? (fetch_flags(vb, bitoff) & actv) : actv;
+        return;
+      }
       if (nact == 64 * R && c.type != T_BOOL) {
         // a complete wave inside an incomplete tile (or a batch-group launch): same code as the FULL instantiation
         fetch_values<true>(c, vals, l, h);
@@ -1066,6 +1081,7 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           const u64* brow = p.group + (int64_t)b * p.group_stride;
           nr = uniform64((int64_t)brow[0]);
           it.ptr_row = brow + 1;
+          if (p.group_bits_at) { it.ptr_bits = brow + p.group_bits_at; it.n_refs_bits = p.pb.n_refs; }
           row0 = ((int64_t)lw - wv) * (64 * R);   // set_rows adds wv * 64 R back
         } else { nr = 0; row0 = 0; it.ptr_row = p.group; }
       } else if (p.group) {   // batch-group launch: the tile's rows and column pointers come from the tile table
@@ -1086,10 +1102,14 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     const uint32_t selv = it.bitsv & it.validv;   // null predicate slot = not selected (arrow prep_null_mask_filter)
     s_sel[buf][tid] = selv;
     if (p.sel_mask) {
+      // single batch: one word per 64 rows of the batch; wave-packed group: one word per slot of every wave slot
+      int64_t gidx = it.w0 >> 6;
+      bool slots = false;
+      if constexpr (PARTIAL) { if (p.group_wpb > 0) { gidx = (tile * NW + wv) * R; slots = true; } }
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const u64 m = __ballot((selv >> j) & 1);
-        if (lane == 0 && it.w0 + 64 * j < p.nrows) p.sel_mask[(it.w0 >> 6) + j] = m;
+        if (lane == 0 && (slots || it.w0 + 64 * j < p.nrows)) p.sel_mask[gidx + j] = m;
       }
     }
     unsigned cnt = __popc(selv);
@@ -1209,10 +1229,13 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     const uint32_t selv = s_sel[buf][tid];
     if (p.grp_base) {
       u64 run = off0;
+      int64_t gidx = w0 >> 6;
+      bool slots = false;
+      if constexpr (PARTIAL) { if (p.group_wpb > 0) { gidx = (tile * NW + wv) * R; slots = true; } }
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const u64 m = __ballot((selv >> j) & 1);
-        if (lane == 0 && w0 + 64 * j < p.nrows) p.grp_base[(w0 >> 6) + j] = run;
+        if (lane == 0 && (slots || w0 + 64 * j < p.nrows)) p.grp_base[gidx + j] = run;
         run += __popcll(m);
       }
     }
@@ -1711,6 +1734,62 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactPara
   }
 }
 
+// The same for a wave-packed batch group (FilterParams::group_bits_at): chunk c is wave slot c of the main launch -- 64 R
+// rows of batch c / wpb -- and reads that batch's bitmap (none: every bit is 1); the output is ONE joined bitmap, batch b's
+// bits are those of its output rows (per-batch results are Arrow slices of it, like the joined Utf8 column).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void bit_compact_group_kernel(const BitCompactGroupParams p) {
+  constexpr int NW = BLOCK / 64;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int64_t nchunks = (int64_t)p.wpb * p.nb;
+  const int R = p.rows_per_wave >> 6;
+  for (int64_t chunk = (int64_t)blockIdx.x * NW + wv; chunk < nchunks; chunk += (int64_t)gridDim.x * NW) {
+    const int64_t b = chunk / p.wpb;
+    const int64_t w0 = (chunk - b * p.wpb) * p.rows_per_wave;          // first row of the chunk inside its batch
+    const u64* brow = p.table + b * p.stride;
+    const int64_t rows = (int64_t)brow[0];
+    if (w0 >= rows) continue;
+    const void* bits = (const void*)brow[p.word_ptr];
+    const int64_t bitoff = (int64_t)brow[p.word_off];
+    const u64 pos0 = p.grp_base[chunk * R];
+    const int shift0 = (int)(pos0 & 31);
+    int64_t wpos = (int64_t)(pos0 >> 5);
+    u64 lo64 = 0; u64 hi64 = 0; int total = shift0;
+    bool head_shared = shift0 != 0;
+    unsigned zeros = 0;
+#pragma unroll 1
+    for (int j = 0; j < R; ++j) {
+      const int64_t r0 = w0 + 64 * j;
+      const u64 act = active_mask(r0, rows);
+      if (!act) break;
+      const u64 m = p.sel_mask[chunk * R + j] & act;
+      const int cnt = __popcll(m);
+      if (cnt == 0) continue;
+      const u64 inb = bits ? load_bits64(bits, bitoff + r0, act) : act;
+      const int mybit = (int)((inb >> lane) & 1);
+      const bool sel = (m >> lane) & 1;
+      const unsigned dst = sel ? lane_rank(m) : 63u - lane_rank(~m);
+      const int got = __builtin_amdgcn_ds_permute((int)(dst << 2), mybit);
+      u64 comp = __ballot(got != 0);
+      if (cnt < 64) comp &= (1ULL << cnt) - 1ULL;
+      zeros += cnt - __popcll(comp);
+      lo64 |= comp << total;
+      hi64 = total ? (comp >> (64 - total)) : 0ULL;
+      total += cnt;
+      while (total >= 32) {
+        const unsigned wordv = (unsigned)lo64;
+        if (lane == 0) { if (head_shared) atomicOr(&p.out_bits[wpos], wordv); else p.out_bits[wpos] = wordv; }
+        head_shared = false;
+        lo64 = (lo64 >> 32) | (hi64 << 32); hi64 >>= 32;
+        total -= 32; ++wpos;
+      }
+    }
+    if (total > 0 && lo64 != 0) { if (lane == 0) atomicOr(&p.out_bits[wpos], (unsigned)lo64); }
+    if (p.zero_count && zeros && lane == 0) atomicAdd(p.zero_count, (u64)zeros);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // utf8_filter_kernel: arrow-select filter of a Utf8 column in one pass.  Tile = 64*G*NW rows.
 //   pass 1: every lane loads the offset of its row (coalesced), lengths of the selected rows come from the
@@ -2097,6 +2176,10 @@ hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, i
 #if CHQ_TU == 0 || CHQ_TU == 4
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL((bit_compact_kernel<256, 8>), dim3(grid), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_bit_compact_group(const BitCompactGroupParams& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((bit_compact_group_kernel<256>), dim3(grid), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 __global__ void gather_i32_kernel(const GatherParams p) {

@@ -231,7 +231,9 @@ def test_reference_schema_group_resident_in_hbm(ctx):
         assert batches_identical(head, exp0, check_nullable=False), sql
 
 
-def test_a_single_null_leaves_the_one_launch_path(ctx):
+def test_a_single_null_stays_on_the_one_launch_path(ctx):
+    """round 3: a device-resident, near-uniform group with validity bitmaps (here: ONE null in one batch) is filtered by the
+    same single launch -- the bitmaps are compacted behind it -- instead of being joined first; host groups still concatenate"""
     recs = [fixed_batch(4000, 80 + i, with_wide=False) for i in range(4)]
     v = recs[2].column(1).to_numpy().copy()
     mask = np.zeros(len(v), dtype=bool)
@@ -241,6 +243,69 @@ def test_a_single_null_leaves_the_one_launch_path(ctx):
     recs[2] = pa.RecordBatch.from_arrays(cols, names=recs[2].schema.names)
     for device in (True, False):
         check_group(ctx, recs, "value1 > 5.0", device)
+    devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]
+    chq.filter_records(devs, empty_aliases(recs[0]), parse_expr("value1 > 5.0"), ctx=ctx)
+    st = ctx.last_stats()
+    assert st["tiles"] < 64 and st["launches"] == 2, st      # the group launch + one bitmap compaction (value1's validity)
+
+
+def nullable_group(nb, rows, seed, null_share=0.2):
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(nb):
+        n = rows - int(rng.integers(0, 40))
+
+        def m(p):
+            return rng.random(n) < p if (b % 3 != 1) else None      # every third batch carries no bitmap at all
+        out.append(pa.RecordBatch.from_arrays([
+            pa.array(rng.integers(-1000, 1000, n).astype(np.int32), mask=m(null_share)),
+            pa.array((rng.random(n) * 100).astype(np.float32), mask=m(0.05)),
+            pa.array(rng.integers(0, 2, n).astype(bool), mask=m(0.3)),
+            pa.array(rng.integers(0, 2, n).astype(bool)),
+            pa.array(rng.integers(-2**40, 2**40, n), type=pa.int64(), mask=m(0.5)),
+            pa.array(["s%d" % v for v in rng.integers(0, 50, n)]),
+            pa.array(rng.integers(0, 200, n).astype(np.uint8)),
+        ], names=["a", "x", "flag", "flag2", "big", "name", "tiny"]))
+    return out
+
+
+@pytest.mark.parametrize("sql", [
+    "tiny > 100",                                   # predicate on a non-null column; five bitmaps ride along
+    "a > 0",                                        # a nullable predicate column: null -> the row is dropped
+    "a + 1 > 0 and x < 50.0",                       # two nullable columns (generic interpreter, validity per batch)
+    "flag",                                         # a nullable Boolean column as the predicate
+    "flag = flag2 or a < 5",
+    "big > 0 and flag2",                            # 64-bit + Boolean
+])
+@pytest.mark.parametrize("rows", [10_000, 3_000])
+def test_device_groups_with_nulls_and_booleans_in_one_launch(ctx, sql, rows):
+    """validity bitmaps (present in some batches only, at their own bit offsets) and Boolean columns of a device-resident,
+    near-uniform group: one group launch + one bitmap compaction per Boolean column / nullable column, outputs identical to
+    the per-batch oracle -- per-batch outputs, joined output, host results, sliced inputs"""
+    recs = nullable_group(9, rows, rows)
+    recs[4] = recs[4].slice(3, recs[4].num_rows - 7)          # Arrow offsets: bitmaps start mid-byte
+    al = empty_aliases(recs[0])
+    e = parse_expr(sql)
+    exp = [O.filter_record(r, al, e) for r in recs]
+    devs = [chq.DeviceRecordBatch.from_host(r, ctx) for r in recs]
+    got = chq.filter_records(devs, al, e, ctx=ctx)
+    st = ctx.last_stats()
+    if "big" not in sql:   # (a 64-bit predicate next to a Utf8 column has no one-launch form: joined on the device)
+        assert st["launches"] <= 1 + 6, st                     # never the join (>= 7 concat launches) nor a per-batch loop
+    for g, x in zip(got, exp):
+        assert batches_identical(g.to_host(), x), explain_diff(g.to_host(), x)
+    host_out = chq.filter_records(devs, al, e, ctx=ctx, device_result=False)
+    for g, x in zip(host_out, exp):
+        assert batches_identical(g, x), explain_diff(g, x)
+    joined, counts = chq.filter_records_coalesced(devs, al, e, ctx=ctx)
+    assert counts == [x.num_rows for x in exp]
+    whole = pa.Table.from_batches(exp).combine_chunks().to_batches()
+    if whole:
+        assert batches_identical(joined.to_host(), whole[0], check_nullable=False)
+    ctx.set_option("group_bits", 0)                            # the join path gives the same answer
+    for g, x in zip(chq.filter_records(devs, al, e, ctx=ctx), exp):
+        assert batches_identical(g.to_host(), x)
+    ctx.set_option("group_bits", 1)
 
 
 def test_group_errors_are_those_of_the_earliest_failing_batch(ctx):
