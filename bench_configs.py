@@ -269,7 +269,7 @@ def main():
         ctx.set_option("trim_pool", 1)
         torch.cuda.empty_cache()
 
-    def run_ref_group_case(name, nb, rows_per_batch, where, seed=5, note=""):
+    def run_ref_group_case(name, nb, rows_per_batch, where, seed=5, note="", null_share=0.0):
         """the reference's own schema (id:Int32, value1:Utf8(8), value2:Float32) in its own batch size, resident in HBM:
         ONE group call (device-side join + the single-batch kernels) against the per-batch loop and the one-batch time"""
         if args.only and args.only not in name:
@@ -285,9 +285,21 @@ def main():
         torch.cuda.synchronize()
         al = [[], [], []]
         pred = parse_expr(where)
-        devs = [chq.DeviceRecordBatch.from_device_pointers(
-            [("id", "i", ids.data_ptr() + 4 * b * rows_per_batch), ("value1", "u", offs.data_ptr(), chars.data_ptr() + L8 * b * rows_per_batch),
-             ("value2", "f", v2.data_ptr() + 4 * b * rows_per_batch)], rows_per_batch, ctx=ctx) for b in range(nb)]
+        valid = None
+        if null_share > 0:   # value2 is an optional column with real nulls (what read_files produces from `optional` Parquet columns)
+            assert rows_per_batch % 8 == 0
+            keepv = torch.rand(n, device=dev, generator=g) >= null_share
+            valid = (keepv.view(-1, 8).to(torch.uint8) << torch.arange(8, device=dev, dtype=torch.uint8)).sum(dim=1).to(torch.uint8)   # LSB-first bitmap
+            torch.cuda.synchronize()
+            devs = [chq.DeviceRecordBatch.from_device_buffers(
+                [{"name": "id", "format": "i", "values": ids.data_ptr() + 4 * b * rows_per_batch},
+                 {"name": "value1", "format": "u", "values": offs.data_ptr(), "data": chars.data_ptr() + L8 * b * rows_per_batch},
+                 {"name": "value2", "format": "f", "nullable": True, "null_count": -1, "values": v2.data_ptr() + 4 * b * rows_per_batch,
+                  "validity": valid.data_ptr() + b * rows_per_batch // 8}], rows_per_batch, ctx=ctx) for b in range(nb)]
+        else:
+            devs = [chq.DeviceRecordBatch.from_device_pointers(
+                [("id", "i", ids.data_ptr() + 4 * b * rows_per_batch), ("value1", "u", offs.data_ptr(), chars.data_ptr() + L8 * b * rows_per_batch),
+                 ("value2", "f", v2.data_ptr() + 4 * b * rows_per_batch)], rows_per_batch, ctx=ctx) for b in range(nb)]
         grp = chq.RecordGroup(devs, ctx)
         # parity: a few batches against the oracle
         got = chq.filter_records(devs[:4], al, pred, ctx=ctx)
@@ -297,7 +309,8 @@ def main():
                 pa.array(ids[lo:lo + rows_per_batch].cpu().numpy()),
                 pa.Array.from_buffers(pa.utf8(), rows_per_batch, [None, pa.py_buffer(offs.cpu().numpy().tobytes()),
                                                                   pa.py_buffer(chars[L8 * lo:L8 * (lo + rows_per_batch)].cpu().numpy().tobytes())]),
-                pa.array(v2[lo:lo + rows_per_batch].cpu().numpy())], names=["id", "value1", "value2"])
+                pa.array(v2[lo:lo + rows_per_batch].cpu().numpy(), mask=None if valid is None else ~keepv[lo:lo + rows_per_batch].cpu().numpy())],
+                names=["id", "value1", "value2"])
             if not batches_identical(got[b].to_host(), O.filter_record(host, al, pred), check_nullable=False):
                 raise SystemExit(f"{name}: batch {b} differs from the oracle")
         del got
@@ -382,6 +395,8 @@ def main():
                   "five such batches")
     run_ref_group_case("refgroup id%2=0, 12 500 x 10k-row batches (1 GB of strings)", 12_500, 10_000, "id % 2 = 0",
                        note="reference schema id:Int32, value1:Utf8(8), value2:Float32; per-batch outputs and the joined output")
+    run_ref_group_case("refgroup with nulls id%2=0, 12 500 x 10k-row batches, value2 optional with 5 % nulls", 12_500, 10_000, "id % 2 = 0",
+                       note="validity bitmaps per batch: the one-launch path + one bitmap compaction (round 3)", null_share=0.05)
     run_ref_group_case("refgroup id%2=0, 100 000 x 10k-row batches", 100_000, 10_000, "id % 2 = 0",
                        note="1 B rows = 8 GB of string bytes: eight joined chunks (int32 offsets), per-batch outputs only")
     if args.out:
