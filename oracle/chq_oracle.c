@@ -29,6 +29,7 @@
 /* ------------------------------------------------------------------ structures */
 struct oc_array {
   int type;
+  int subtype;                /* temporal / decimal types: DataType parameters as an id (equal ids <=> equal DataTypes) */
   int64_t length;
   int64_t null_count;
   const void* values;         /* fixed: typed values; bool: bitmap; utf8: int32 offsets */
@@ -64,9 +65,10 @@ struct oc_expr {
 
 typedef struct { oc_array* arr; int is_scalar; int borrowed; } datum;
 
-static const int TYPE_WIDTH[OC_NTYPES] = {0, 1, 2, 4, 8, 1, 2, 4, 8, 2, 4, 8, 0};
+static const int TYPE_WIDTH[OC_NTYPES] = {0, 1, 2, 4, 8, 1, 2, 4, 8, 2, 4, 8, 0, 4, 8, 4, 8, 8, 8, 16};
 static const char* TYPE_NAME[OC_NTYPES] = {"Boolean", "Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16",
-                                           "UInt32", "UInt64", "Float16", "Float32", "Float64", "Utf8"};
+                                           "UInt32", "UInt64", "Float16", "Float32", "Float64", "Utf8",
+                                           "Date32", "Date64", "Time32", "Time64", "Timestamp", "Duration", "Decimal128"};
 
 static int fail(char* err, int errlen, int code, const char* fmt, ...) {
   if (err && errlen > 0) {
@@ -153,6 +155,11 @@ int oc_batch_set_column(oc_batch* b, int idx, const char* name, int type, int nu
   b->cols[idx] = a; b->cols_owned[idx] = 1;
   return OC_OK;
 }
+int oc_batch_set_column_subtype(oc_batch* b, int idx, int subtype) {
+  if (idx < 0 || idx >= b->ncols || !b->cols[idx]) return OC_ERR_ARROW_INVALID_ARGUMENT;
+  b->cols[idx]->subtype = subtype;
+  return OC_OK;
+}
 int oc_batch_set_aliases(oc_batch* b, int idx, const char* const* aliases, int n) {
   if (idx < 0 || idx >= b->ncols) return OC_ERR_ARROW_INVALID_ARGUMENT;
   for (int k = 0; k < b->nalias[idx]; ++k) free(b->aliases[idx][k]);
@@ -180,6 +187,7 @@ const char* oc_batch_field_name(const oc_batch* b, int idx) { return b->names[id
 int oc_batch_field_nullable(const oc_batch* b, int idx) { return b->nullable[idx]; }
 const oc_array* oc_batch_column(const oc_batch* b, int idx) { return b->cols[idx]; }
 int oc_array_type(const oc_array* a) { return a->type; }
+int oc_array_subtype(const oc_array* a) { return a->subtype; }
 int64_t oc_array_length(const oc_array* a) { return a->length; }
 int64_t oc_array_null_count(const oc_array* a) { return a->null_count; }
 const void* oc_array_values(const oc_array* a) { return a->values; }
@@ -231,8 +239,43 @@ static int scalar_of(int type, const void* v, datum* out) {
 /* ------------------------------------------------------------------ arrow-cast: compute::cast */
 #define LOADV(T, a, i) (((const T*)(a)->values)[(i)])
 
+/* Float16 <-> f32 as the `half` crate (2.x, arrow's f16) converts: widening is exact and quiets a signalling NaN;
+ * narrowing rounds to nearest even, NaN keeps its top payload bits with the quiet bit set.  f16 arithmetic in
+ * arrow-arith is half's operator impls: from_f32(to_f32(a) OP to_f32(b)).  (unpinned-by-reference: the reference
+ * holds no Float16 vector.) */
+static float h2f(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = h & 0x7C00u, man = h & 0x03FFu, b;
+  if ((h & 0x7FFFu) == 0) b = sign;
+  else if (exp == 0x7C00u) b = man == 0 ? (sign | 0x7F800000u) : (sign | 0x7FC00000u | (man << 13));
+  else if (exp == 0) {   /* subnormal: normalise */
+    int e = 0; while (!(man & 0x0400u)) { man <<= 1; ++e; }
+    b = sign | (uint32_t)(127 - 15 - e + 1) << 23 | ((man & 0x03FFu) << 13);
+  } else b = sign | (((exp >> 10) + (127 - 15)) << 23) | (man << 13);
+  float f; memcpy(&f, &b, 4); return f;
+}
+static uint16_t f2h(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  uint32_t sign = x & 0x80000000u, exp = x & 0x7F800000u, man = x & 0x007FFFFFu;
+  if (exp == 0x7F800000u) return (uint16_t)((sign >> 16) | 0x7C00u | (man ? 0x0200u : 0) | (man >> 13));
+  uint32_t hs = sign >> 16;
+  int32_t e = (int32_t)(exp >> 23) - 127 + 15;
+  if (e >= 0x1F) return (uint16_t)(hs | 0x7C00u);            /* overflow -> infinity */
+  if (e <= 0) {                                              /* subnormal or zero */
+    if (14 - e > 24) return (uint16_t)hs;
+    man |= 0x00800000u;
+    uint32_t hm = man >> (14 - e);
+    uint32_t round_bit = 1u << (13 - e);
+    if ((man & round_bit) && (man & (3 * round_bit - 1))) ++hm;
+    return (uint16_t)(hs | hm);
+  }
+  uint32_t he = (uint32_t)e << 10, hm = man >> 13, round_bit = 0x00001000u;
+  if ((man & round_bit) && (man & (3 * round_bit - 1))) return (uint16_t)((hs | he | hm) + 1);
+  return (uint16_t)(hs | he | hm);
+}
+
 static double load_as_f64(const oc_array* a, int64_t i) {
   switch (a->type) {
+    case OC_F16: return h2f(LOADV(uint16_t, a, i));
     case OC_I8: return LOADV(int8_t, a, i); case OC_I16: return LOADV(int16_t, a, i);
     case OC_I32: return LOADV(int32_t, a, i); case OC_I64: return (double)LOADV(int64_t, a, i);
     case OC_U8: return LOADV(uint8_t, a, i); case OC_U16: return LOADV(uint16_t, a, i);
@@ -243,7 +286,7 @@ static double load_as_f64(const oc_array* a, int64_t i) {
 }
 static int is_int_type(int t) { return t >= OC_I8 && t <= OC_U64; }
 static int is_signed_int(int t) { return t >= OC_I8 && t <= OC_I64; }
-static int is_float_type(int t) { return t == OC_F32 || t == OC_F64; }
+static int is_float_type(int t) { return t == OC_F16 || t == OC_F32 || t == OC_F64; }
 
 static oc_array* copy_validity_from(oc_array* dst, const oc_array* src) {
   if (src->validity && src->null_count > 0) {
@@ -254,12 +297,45 @@ static oc_array* copy_validity_from(oc_array* dst, const oc_array* src) {
   return dst;
 }
 
+/* Rust's char::is_whitespace (Unicode White_Space) at the start / end of a UTF-8 byte string: length of the
+ * white-space character that starts at p (0 = none) / that ends just before p + n */
+static int ws_at(const uint8_t* p, int64_t n) {
+  if (n >= 1 && ((p[0] >= 0x09 && p[0] <= 0x0D) || p[0] == 0x20)) return 1;
+  if (n >= 2 && p[0] == 0xC2 && (p[1] == 0x85 || p[1] == 0xA0)) return 2;
+  if (n >= 3) {
+    if (p[0] == 0xE1 && p[1] == 0x9A && p[2] == 0x80) return 3;                                   /* U+1680 */
+    if (p[0] == 0xE2 && p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) return 3;
+    if (p[0] == 0xE2 && p[1] == 0x81 && p[2] == 0x9F) return 3;                                   /* U+205F */
+    if (p[0] == 0xE3 && p[1] == 0x80 && p[2] == 0x80) return 3;                                   /* U+3000 */
+  }
+  return 0;
+}
+static int ws_before(const uint8_t* p, int64_t n) {
+  for (int w = 1; w <= 3 && w <= n; ++w) if (ws_at(p + n - w, w) == w) return w;
+  return 0;
+}
+/* 1 / 0 / -1 (not a boolean spelling) */
+static int utf8_bool(const uint8_t* p, int64_t n) {
+  int w;
+  while (n > 0 && (w = ws_at(p, n)) > 0) { p += w; n -= w; }
+  while (n > 0 && (w = ws_before(p, n)) > 0) n -= w;
+  char buf[8];
+  if (n < 1 || n > 5) return -1;
+  for (int64_t i = 0; i < n; ++i) buf[i] = (char)((p[i] >= 'A' && p[i] <= 'Z') ? p[i] + 32 : p[i]);
+  buf[n] = 0;
+  static const char* T[] = {"t", "tr", "tru", "true", "y", "ye", "yes", "on", "1"};
+  static const char* F[] = {"f", "fa", "fal", "fals", "false", "n", "no", "of", "off", "0"};
+  for (size_t k = 0; k < sizeof T / sizeof *T; ++k) if ((int64_t)strlen(T[k]) == n && !memcmp(buf, T[k], (size_t)n)) return 1;
+  for (size_t k = 0; k < sizeof F / sizeof *F; ++k) if ((int64_t)strlen(F[k]) == n && !memcmp(buf, F[k], (size_t)n)) return 0;
+  return -1;
+}
+
 /* cast numeric -> numeric (as-style; safe mode nulls unrepresentable values, which the widening-only
  * coercion table never produces), numeric -> Boolean (value != 0), same type -> clone. */
 static int arrow_cast(const oc_array* a, int to, oc_array** out, char* err, int errlen) {
   int from = a->type;
   int64_t n = a->length;
-  if (from == OC_F16 || to == OC_F16) return fail(err, errlen, OC_ERR_NOT_SUPPORTED, "Float16 is not supported by the oracle");
+  if (to == OC_F16 && from != OC_F16) return fail(err, errlen, OC_ERR_NOT_SUPPORTED, "casts to Float16 are never requested by the coercion table");
   if (from == to) {
     oc_array* r;
     if (from == OC_UTF8) {
@@ -278,7 +354,26 @@ static int arrow_cast(const oc_array* a, int to, oc_array** out, char* err, int 
       r = arr_alloc_fixed(from, n);
       memcpy((void*)r->values, a->values, (size_t)n * (size_t)TYPE_WIDTH[from]);
     }
+    r->subtype = a->subtype;
     copy_validity_from(r, a);
+    *out = r; return OC_OK;
+  }
+  if (to == OC_BOOL && from == OC_UTF8) {
+    /* arrow-cast 53 cast_utf8_to_boolean (reached from compute_value.rs:72-73 / :95-96): value.to_ascii_lowercase().trim()
+     * matched against the accepted spellings; anything else is NULL because compute::cast runs with safe = true.
+     * (unpinned-by-reference: the reference's tests never put a string under AND / OR.) */
+    oc_array* r = arr_alloc_fixed(OC_BOOL, n);
+    uint8_t* v = (uint8_t*)calloc((size_t)((n + 7) / 8) + 8, 1);
+    int64_t nc = 0;
+    const int32_t* off = (const int32_t*)a->values;
+    for (int64_t i = 0; i < n; ++i) {
+      int val = -1;
+      if (arr_valid(a, i)) val = utf8_bool(a->data + off[i], off[i + 1] - off[i]);
+      if (val < 0) { ++nc; continue; }
+      bit_set(v, i);
+      if (val) bit_set((uint8_t*)r->values, i);
+    }
+    if (nc > 0) { r->validity = v; r->null_count = nc; } else free(v);
     *out = r; return OC_OK;
   }
   if (to == OC_BOOL && (is_int_type(from) || is_float_type(from))) {
@@ -400,7 +495,8 @@ static int get_common_type(int l, int r, int* out) {
 /* cast_to_common_type (compute_value.rs:433-461): returns new datums (borrowing when no cast is needed) */
 static int cast_to_common_type(const datum* l, const datum* r, datum* lo, datum* ro, char* err, int errlen) {
   int ct;
-  if (!get_common_type(l->arr->type, r->arr->type, &ct))
+  if (!get_common_type(l->arr->type, r->arr->type, &ct) ||
+      (l->arr->type == r->arr->type && l->arr->subtype != r->arr->subtype))   /* e.g. Timestamp(s) vs Timestamp(ms): different DataTypes */
     return fail(err, errlen, OC_ERR_UNSUPPORTED_TYPE_COERSION, "unsupported type coersion for operation between types %s and %s",
                 TYPE_NAME[l->arr->type], TYPE_NAME[l->arr->type]);
   lo->is_scalar = l->is_scalar; ro->is_scalar = r->is_scalar;
@@ -470,6 +566,11 @@ static const char* AR_SYM[] = {"+", "-", "*", "/", "%"};
 
 static int arrow_arith(int op, const datum* l, const datum* r, oc_array** res, char* err, int errlen) {
   int t = l->arr->type;
+  /* arrow-arith 53 numeric.rs arithmetic_op: Decimal128 and Duration (+) have arithmetic the oracle does not restate;
+   * Date / Timestamp / Duration reject + * / % (only subtraction-like forms exist), Time32/64 have no arithmetic. */
+  if (t == r->arr->type && (t == OC_DECIMAL128 || (t == OC_DURATION && (op == AR_ADD || op == AR_SUB)) ||
+                            ((t == OC_DATE32 || t == OC_DATE64 || t == OC_TIMESTAMP) && op == AR_SUB)))
+    return fail(err, errlen, OC_ERR_NOT_SUPPORTED, "%s arithmetic is not restated by the oracle", TYPE_NAME[t]);
   if (t != r->arr->type || !(is_int_type(t) || is_float_type(t)))
     return fail(err, errlen, OC_ERR_ARROW_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s", TYPE_NAME[t], AR_SYM[op], TYPE_NAME[r->arr->type]);
   int64_t n; int rc = binary_shape(l, r, &n, err, errlen, "perform a binary operation on");
@@ -486,6 +587,14 @@ static int arrow_arith(int op, const datum* l, const datum* r, oc_array** res, c
     case OC_U16: INT_ARITH(uint16_t, int64_t, 0, UINT16_MAX, 0) break;
     case OC_U32: INT_ARITH(uint32_t, int64_t, 0, UINT32_MAX, 0) break;
     case OC_U64: INT_ARITH(uint64_t, __int128, 0, UINT64_MAX, 0) break;
+    case OC_F16:
+      for (int64_t i = 0; i < n; ++i) {
+        float a = h2f(((const uint16_t*)l->arr->values)[lb ? 0 : i]), b = h2f(((const uint16_t*)r->arr->values)[rb ? 0 : i]), w;
+        switch (op) { case AR_ADD: w = a + b; break; case AR_SUB: w = a - b; break; case AR_MUL: w = a * b; break;
+                      case AR_DIV: w = a / b; break; default: w = fmodf(a, b); break; }
+        ((uint16_t*)out->values)[i] = f2h(w);
+      }
+      break;
     case OC_F32:
       for (int64_t i = 0; i < n; ++i) {
         float a = ((const float*)l->arr->values)[lb ? 0 : i], b = ((const float*)r->arr->values)[rb ? 0 : i], w;
@@ -523,7 +632,7 @@ static inline int cmp_result(int op, int lt, int eq) {
 static int arrow_cmp(int op, const datum* l, const datum* r, oc_array** res, char* err, int errlen) {
   static const char* SYM[] = {"==", "!=", "<", "<=", ">", ">="};
   int t = l->arr->type;
-  if (t != r->arr->type || t == OC_F16)
+  if (t != r->arr->type)
     return fail(err, errlen, OC_ERR_ARROW_INVALID_ARGUMENT, "Invalid comparison operation: %s %s %s", TYPE_NAME[t], SYM[op], TYPE_NAME[r->arr->type]);
   int64_t n; int rc = binary_shape(l, r, &n, err, errlen, "compare");
   if (rc) return rc;
@@ -538,6 +647,12 @@ static int arrow_cmp(int op, const datum* l, const datum* r, oc_array** res, cha
       CASE(OC_I8, int8_t) CASE(OC_I16, int16_t) CASE(OC_I32, int32_t) CASE(OC_I64, int64_t)
       CASE(OC_U8, uint8_t) CASE(OC_U16, uint16_t) CASE(OC_U32, uint32_t) CASE(OC_U64, uint64_t)
 #undef CASE
+      /* temporal / decimal primitives compare their raw values (i32 / i64 / i128 natives) */
+      case OC_DATE32: case OC_TIME32: { int32_t a = LOADV(int32_t, l->arr, li), b = LOADV(int32_t, r->arr, ri); lt = a < b; eq = a == b; } break;
+      case OC_DATE64: case OC_TIME64: case OC_TIMESTAMP: case OC_DURATION: { int64_t a = LOADV(int64_t, l->arr, li), b = LOADV(int64_t, r->arr, ri); lt = a < b; eq = a == b; } break;
+      case OC_DECIMAL128: { __int128 a, b; memcpy(&a, (const uint8_t*)l->arr->values + 16 * li, 16); memcpy(&b, (const uint8_t*)r->arr->values + 16 * ri, 16); lt = a < b; eq = a == b; } break;
+      case OC_F16: { int16_t a = LOADV(int16_t, l->arr, li), b = LOADV(int16_t, r->arr, ri);   /* f16::total_cmp */
+                     a ^= (int16_t)(((uint16_t)(a >> 15)) >> 1); b ^= (int16_t)(((uint16_t)(b >> 15)) >> 1); lt = a < b; eq = a == b; } break;
       case OC_F32: { int32_t a = f32_key(LOADV(float, l->arr, li)), b = f32_key(LOADV(float, r->arr, ri)); lt = a < b; eq = a == b; } break;
       case OC_F64: { int64_t a = f64_key(LOADV(double, l->arr, li)), b = f64_key(LOADV(double, r->arr, ri)); lt = a < b; eq = a == b; } break;
       case OC_BOOL: { int a = arr_bool(l->arr, li), b = arr_bool(r->arr, ri); lt = a < b; eq = a == b; } break;
@@ -590,7 +705,6 @@ static int compute_value_rec(const oc_batch* rec, const oc_expr* e, datum* out, 
       if (e->op == OC_OP_AND || e->op == OC_OP_OR) {
         /* compute_value.rs:71-116: cast both sides to Boolean, then non-Kleene and/or; is_scalar=false */
         oc_array *lbool = NULL, *rbool = NULL;
-        if (l.arr->type == OC_UTF8 || r.arr->type == OC_UTF8) rc = fail(err, errlen, OC_ERR_NOT_SUPPORTED, "Utf8 -> Boolean cast is not supported by the oracle");
         if (!rc) rc = arrow_cast(l.arr, OC_BOOL, &lbool, err, errlen);
         if (!rc) rc = arrow_cast(r.arr, OC_BOOL, &rbool, err, errlen);
         if (!rc) rc = arrow_and_or(e->op == OC_OP_AND, lbool, rbool, &out->arr, err, errlen);
@@ -715,6 +829,7 @@ static oc_array* filter_array(const oc_array* a, const oc_array* mask, int64_t c
   } else {
     int w = TYPE_WIDTH[a->type];
     r = arr_alloc_fixed(a->type, count);
+    r->subtype = a->subtype;
     const uint8_t* src = (const uint8_t*)a->values; uint8_t* dst = (uint8_t*)r->values;
     for (int64_t i = 0; i < m; ++i) if (SEL(i)) { memcpy(dst + k * w, src + i * w, (size_t)w); ++k; }
   }

@@ -26,7 +26,11 @@ extern "C" {
 /* data types (subset of arrow DataType that compute_value.rs:350-431 can coerce) */
 enum {
   OC_BOOL = 0, OC_I8, OC_I16, OC_I32, OC_I64, OC_U8, OC_U16, OC_U32, OC_U64,
-  OC_F16, OC_F32, OC_F64, OC_UTF8, OC_NTYPES
+  OC_F16, OC_F32, OC_F64, OC_UTF8,
+  /* temporal / decimal primitives: copied by filters and projections, compared with the SAME type only
+   * (get_common_type's `_ if left == right` arm, compute_value.rs:355; `subtype` carries unit / time zone /
+   * precision+scale so that DataType equality can be decided) */
+  OC_DATE32, OC_DATE64, OC_TIME32, OC_TIME64, OC_TIMESTAMP, OC_DURATION, OC_DECIMAL128, OC_NTYPES
 };
 
 /* sqlparser::ast::BinaryOperator subset; anything else -> OC_OP_OTHER */
@@ -83,6 +87,8 @@ oc_batch* oc_batch_new(int ncols, int64_t nrows);
 int oc_batch_set_column(oc_batch* b, int idx, const char* name, int type, int nullable,
                         const void* values, int64_t bit_offset, const uint8_t* data,
                         const uint8_t* validity, int64_t validity_bit_offset);
+/* DataType parameters of a temporal / decimal column as one caller-chosen id (equal ids <=> equal DataTypes) */
+int oc_batch_set_column_subtype(oc_batch* b, int idx, int subtype);
 int oc_batch_set_aliases(oc_batch* b, int idx, const char* const* aliases, int n);
 /* leave aliases shorter than the column count (test_compute_value.rs passes vec![]) */
 void oc_batch_truncate_aliases(oc_batch* b, int n);
@@ -95,6 +101,7 @@ int oc_batch_field_nullable(const oc_batch* b, int idx);
 const oc_array* oc_batch_column(const oc_batch* b, int idx);
 
 int oc_array_type(const oc_array* a);
+int oc_array_subtype(const oc_array* a);
 int64_t oc_array_length(const oc_array* a);
 int64_t oc_array_null_count(const oc_array* a);
 const void* oc_array_values(const oc_array* a);      /* fixed: values; bool: bitmap; utf8: offsets */

@@ -25,8 +25,31 @@ _LIB_PATH = os.path.join(_HERE, "libchq_oracle.so")
 
 OC_TYPES = [pa.bool_(), pa.int8(), pa.int16(), pa.int32(), pa.int64(), pa.uint8(), pa.uint16(), pa.uint32(),
             pa.uint64(), pa.float16(), pa.float32(), pa.float64(), pa.utf8()]
-_WIDTH = [0, 1, 2, 4, 8, 1, 2, 4, 8, 2, 4, 8, 0]
+_WIDTH = [0, 1, 2, 4, 8, 1, 2, 4, 8, 2, 4, 8, 0, 4, 8, 4, 8, 8, 8, 16]
 OC_UTF8, OC_BOOL = 12, 0
+OC_DATE32, OC_DATE64, OC_TIME32, OC_TIME64, OC_TIMESTAMP, OC_DURATION, OC_DECIMAL128 = range(13, 20)
+
+# temporal / decimal DataTypes: (oracle type, subtype id); the id is the position of the pyarrow type in _SUBTYPES, so
+# equal ids <=> equal DataTypes (unit, time zone, precision and scale included), which is all get_common_type needs
+_SUBTYPES: list = []
+
+
+def _oc_type(t: pa.DataType):
+    if t in OC_TYPES:
+        return OC_TYPES.index(t), 0
+    T = pa.types
+    kind = (OC_DATE32 if T.is_date32(t) else OC_DATE64 if T.is_date64(t) else OC_TIME32 if T.is_time32(t) else
+            OC_TIME64 if T.is_time64(t) else OC_TIMESTAMP if T.is_timestamp(t) else OC_DURATION if T.is_duration(t) else
+            OC_DECIMAL128 if T.is_decimal128(t) else None)
+    if kind is None:
+        raise OracleError(30, f"type {t} is outside the oracle's scope")
+    if t not in _SUBTYPES:
+        _SUBTYPES.append(t)
+    return kind, _SUBTYPES.index(t) + 1
+
+
+def _pa_type(t: int, subtype: int) -> pa.DataType:
+    return OC_TYPES[t] if t < len(OC_TYPES) else _SUBTYPES[subtype - 1]
 
 _OPS = {A.BinaryOperator.And: 0, A.BinaryOperator.Or: 1, A.BinaryOperator.Plus: 2, A.BinaryOperator.Minus: 3,
         A.BinaryOperator.Multiply: 4, A.BinaryOperator.Divide: 5, A.BinaryOperator.Modulo: 6,
@@ -70,6 +93,7 @@ def lib():
         "oc_expr_other": (vp, [cp]), "oc_expr_free": (None, [vp]),
         "oc_batch_new": (vp, [C.c_int, i64]),
         "oc_batch_set_column": (C.c_int, [vp, C.c_int, cp, C.c_int, C.c_int, vp, i64, vp, vp, i64]),
+        "oc_batch_set_column_subtype": (C.c_int, [vp, C.c_int, C.c_int]), "oc_array_subtype": (C.c_int, [vp]),
         "oc_batch_set_aliases": (C.c_int, [vp, C.c_int, C.POINTER(cp), C.c_int]),
         "oc_batch_truncate_aliases": (None, [vp, C.c_int]), "oc_batch_free": (None, [vp]),
         "oc_batch_num_columns": (C.c_int, [vp]), "oc_batch_num_rows": (i64, [vp]),
@@ -148,10 +172,7 @@ class _Batch:
         for i in range(rec.num_columns):
             col = rec.column(i)
             fld = rec.schema.field(i)
-            try:
-                t = OC_TYPES.index(col.type)
-            except ValueError:
-                raise OracleError(30, f"type {col.type} is outside the oracle's scope")
+            t, subtype = _oc_type(col.type)
             bufs = col.buffers()
             off = col.offset
             validity = bufs[0].address if bufs[0] is not None else None
@@ -167,6 +188,8 @@ class _Batch:
                                        validity, off)
             if rc:
                 raise OracleError(rc, "oc_batch_set_column failed")
+            if subtype:
+                L.oc_batch_set_column_subtype(self.h, i, subtype)
         if table_aliases is not None:
             for i, al in enumerate(table_aliases[: rec.num_columns]):
                 arr = (C.c_char_p * max(1, len(al)))(*[a.encode() for a in al])
@@ -192,7 +215,7 @@ def _array_to_pa(h) -> pa.Array:
     t = L.oc_array_type(h)
     n = L.oc_array_length(h)
     nc = L.oc_array_null_count(h)
-    typ = OC_TYPES[t]
+    typ = _pa_type(t, L.oc_array_subtype(h))
     vaddr = L.oc_array_validity(h)
     validity = None
     if vaddr and nc > 0:

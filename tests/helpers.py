@@ -76,7 +76,10 @@ def arrays_identical(a: pa.Array, b: pa.Array, nan_payload: bool = True) -> bool
             na, nb = np.isnan(fa[va]), np.isnan(fb[vb])
             return bool(np.array_equal(na, nb) and np.array_equal(xa[~na], xb[~nb]))
         return bool(np.array_equal(xa, xb))
-    if pa.types.is_string(a.type) or pa.types.is_boolean(a.type):
+    if pa.types.is_temporal(a.type):   # raw values (a timestamp may lie outside datetime's range)
+        raw = pa.int32() if a.type.bit_width == 32 else pa.int64()
+        return a.view(raw).to_pylist() == b.view(raw).to_pylist()
+    if pa.types.is_string(a.type) or pa.types.is_boolean(a.type) or pa.types.is_decimal(a.type):
         return a.to_pylist() == b.to_pylist()
     xa = a.fill_null(0).to_numpy(zero_copy_only=False)
     xb = b.fill_null(0).to_numpy(zero_copy_only=False)

@@ -68,6 +68,55 @@ def batch_strings():
     ], names=["s", "r", "id"])
 
 
+def batch_temporal():
+    """Same-type temporal / decimal pairs (compared on their raw i32 / i64 / i128 values) next to columns whose DataType
+    differs in unit, time zone, precision or scale only."""
+    D = __import__("decimal").Decimal
+    big = 2**70
+    return pa.RecordBatch.from_arrays([
+        pa.array([0, 19000, -5, None, 7, 7], pa.date32()), pa.array([1, 18999, -5, 3, None, 6], pa.date32()),
+        pa.array([0, 86400000, -86400000, 5, 5, 6], pa.date64()), pa.array([0, 0, 0, 5, 6, 5], pa.date64()),
+        pa.array([10, 20, 2**40, -2**40, None, 0], pa.timestamp("s")), pa.array([10, 21, 2**40 - 1, -2**40 + 1, 3, 0], pa.timestamp("s")),
+        pa.array([10, 20, 30, 40, 50, 60], pa.timestamp("ms")),
+        pa.array([10, 20, 30, 40, 50, 60], pa.timestamp("s", tz="UTC")),
+        pa.array([1, 2, 3, 4, 5, 6], pa.time32("s")), pa.array([6, 5, 3, 2, 1, 0], pa.time32("s")),
+        pa.array([1, 2, 3, 4, 5, 6], pa.time64("us")), pa.array([6, 5, 3, 2, 1, 0], pa.time64("us")),
+        pa.array([-1, 0, 1, 2, 3, None], pa.duration("ms")), pa.array([0, 0, 0, 3, 3, 3], pa.duration("ms")),
+        pa.array([D(big) / 100, D(-big) / 100, D("1.50"), D("-0.01"), None, D(big + 1) / 100], pa.decimal128(30, 2)),
+        pa.array([D(big + 1) / 100, D(-big - 1) / 100, D("1.50"), D("0.00"), D("1.00"), D(big) / 100], pa.decimal128(30, 2)),
+        pa.array([D("1.500")] * 6, pa.decimal128(30, 3)),
+        pa.array([1, 2, 3, 4, 5, 6], pa.int32()),
+    ], names=["d1", "d2", "e1", "e2", "ts1", "ts2", "tms", "tz", "t1", "t2", "u1", "u2", "du1", "du2", "dec1", "dec2", "dec3", "id"])
+
+
+def _f16(vals):
+    return pa.array(np.array(vals, dtype=np.float16), pa.float16())
+
+
+def _f16_bits(bits):
+    return pa.array(np.array(bits, dtype=np.uint16).view(np.float16), pa.float16())
+
+
+def batch_halves():
+    return pa.RecordBatch.from_arrays([
+        #          -0.0    0.0     NaN     -NaN    inf     1.5     2048    65504 (max)  6e-8 (min subnormal)  0.1 (rounded)
+        _f16_bits([0x8000, 0x0000, 0x7E00, 0xFE00, 0x7C00, 0x3E00, 0x6800, 0x7BFF, 0x0001, 0x2E66]),
+        _f16_bits([0x0000, 0x8000, 0x7E00, 0x7E00, 0x7C00, 0x3E00, 0x3C00, 0x7BFF, 0x0001, 0x3C00]),
+        pa.array(np.array([0.0, 0.0, 1.0, 1.0, 1e38, 1.5, 2048.5, 65504.0, 6e-8, 0.1], dtype=np.float32)),
+        pa.array(np.array([0.0, 0.0, 1.0, 1.0, 1e300, 1.5, 2048.5, 65504.0, 6e-8, 0.1], dtype=np.float64)),
+        pa.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10], pa.int32()),
+        pa.array([True, True, True, False, True, None, True, True, True, True], pa.bool_()),
+    ], names=["h", "k", "f", "d", "i", "t"])
+
+
+def batch_bool_words():
+    return pa.RecordBatch.from_arrays([
+        pa.array(["true", " YES ", "0", "off", "maybe", None, "\u2003t\u00a0", "TRU", "", "of", "tr ue", "1", "\tfAlSe\n", "no\u3000", "2", "yess"], pa.utf8()),
+        pa.array([True, True, True, True, True, True, False, None, True, True, True, False, True, True, True, True], pa.bool_()),
+        pa.array(list(range(16)), pa.int32()),
+    ], names=["s", "b", "id"])
+
+
 # (name, batch factory, kind, sql / select, expectation)
 # kind "value": expectation = (arrow type, python list)   [compute_value]
 # kind "filter": expectation = list of surviving row indices of the input batch
@@ -151,6 +200,55 @@ RULES = [
     ("utf8_scalar_on_the_left", batch_strings, "value", "'ab' < s", (pa.bool_(), [True, False, False, False, True, True, False])),
     ("utf8_column_vs_column", batch_strings, "value", "s <= r", (pa.bool_(), [True, True, True, False, False, False, True])),
     ("utf8_filter_mixed", batch_strings, "filter", "s <> 'b' and id % 2 = 0", [2, 4, 6]),
+    # ---- same-type temporal / decimal comparisons (get_common_type's `left == right` arm, compute_value.rs:355; arrow-ord
+    # compares the native i32 / i64 / i128 values).  unpinned-by-reference ------------------------------------------
+    ("date32_lt", batch_temporal, "value", "d1 < d2", (pa.bool_(), [True, False, False, None, None, False])),
+    ("date32_gteq", batch_temporal, "value", "d1 >= d2", (pa.bool_(), [False, True, True, None, None, True])),
+    ("date64_eq", batch_temporal, "value", "e1 = e2", (pa.bool_(), [True, False, False, True, False, False])),
+    ("date64_lt_negative", batch_temporal, "value", "e1 < e2", (pa.bool_(), [False, False, True, False, True, False])),
+    ("timestamp_lteq", batch_temporal, "value", "ts1 <= ts2", (pa.bool_(), [True, True, False, True, None, True])),
+    ("timestamp_neq", batch_temporal, "value", "ts1 <> ts2", (pa.bool_(), [False, True, True, True, None, False])),
+    ("time32_gt", batch_temporal, "value", "t1 > t2", (pa.bool_(), [False, False, False, True, True, True])),
+    ("time64_lteq", batch_temporal, "value", "u1 <= u2", (pa.bool_(), [True, True, True, False, False, False])),
+    ("duration_lt", batch_temporal, "value", "du1 < du2", (pa.bool_(), [True, False, False, True, False, None])),
+    ("decimal128_lt_uses_all_128_bits", batch_temporal, "value", "dec1 < dec2", (pa.bool_(), [True, False, False, True, None, False])),
+    ("decimal128_eq", batch_temporal, "value", "dec1 = dec2", (pa.bool_(), [False, False, True, False, None, False])),
+    ("decimal128_gteq", batch_temporal, "value", "dec2 >= dec1", (pa.bool_(), [True, False, True, True, None, False])),
+    ("date32_filter_keeps_every_column", batch_temporal, "filter", "d1 < d2", [0]),
+    ("decimal128_filter", batch_temporal, "filter", "dec1 < dec2 or id = 3", [0, 2, 3]),
+    ("timestamp_filter_mixed", batch_temporal, "filter", "ts1 <= ts2 and id > 1", [1, 3, 5]),
+    ("timestamp_units_differ", batch_temporal, "error", "ts1 < tms", 9),
+    ("timestamp_time_zones_differ", batch_temporal, "error", "ts1 < tz", 9),
+    ("decimal_scales_differ", batch_temporal, "error", "dec1 < dec3", 9),
+    ("date32_vs_date64", batch_temporal, "error", "d1 < e1", 9),
+    ("date_vs_literal", batch_temporal, "error", "d1 < 5", 9),
+    ("date_plus_date_invalid", batch_temporal, "error", "d1 + d2", 22),
+    ("time_times_time_invalid", batch_temporal, "error", "t1 * t2", 22),
+    ("duration_rem_invalid", batch_temporal, "error", "du1 % du2", 22),
+    ("date_under_and_cannot_cast", batch_temporal, "error", "d1 and id > 1", 24),
+    # ---- Float16: total order on the raw halves, exact widening, arithmetic = f32 operation rounded back to f16 -----
+    ("f16_lt_total_order", batch_halves, "value", "h < k", (pa.bool_(), [True, False, False, True, False, False, False, False, False, True])),
+    ("f16_eq_is_bitwise", batch_halves, "value", "h = k", (pa.bool_(), [False, False, True, False, True, True, False, True, True, False])),
+    ("f16_gteq_total_order", batch_halves, "value", "h >= k", (pa.bool_(), [False, True, True, False, True, True, True, True, True, False])),
+    ("f16_widens_to_f32", batch_halves, "value", "h < f", (pa.bool_(), [True, False, False, True, False, False, True, False, True, True])),
+    ("f16_widens_to_f64", batch_halves, "value", "h = d", (pa.bool_(), [False, True, False, False, False, True, False, True, False, False])),
+    ("f16_with_f32_literal", batch_halves, "value", "k * 0.5", (pa.float32(), [0.0, -0.0, NAN, NAN, INF, 0.75, 0.5, 32752.0, 2.9802322387695312e-08, 0.5])),
+    ("f16_add_rounds_to_nearest_even", batch_halves, "value", "h + k", (pa.float16(), [0.0, 0.0, NAN, NAN, INF, 3.0, 2048.0, INF, 1.1920928955078125e-07, 1.0996094])),
+    ("f16_mul", batch_halves, "value", "h * k", (pa.float16(), [-0.0, -0.0, NAN, NAN, INF, 2.25, 2048.0, INF, 0.0, 0.099975586])),
+    ("f16_div_by_zero_is_ieee", batch_halves, "value", "k / h", (pa.float16(), [NAN, NAN, NAN, NAN, NAN, 1.0, 0.00048828125, 1.0, 1.0, 10.0])),
+    ("f16_filter", batch_halves, "filter", "h < k", [0, 3, 9]),
+    ("f16_under_and_casts_to_bool", batch_halves, "value", "h and t", (pa.bool_(), [False, False, True, False, True, None, True, True, True, True])),
+    ("f16_with_int_unsupported", batch_halves, "error", "h + i", 9),
+    ("f16_with_int_literal_unsupported", batch_halves, "error", "h < 1", 9),
+    # ---- Utf8 under AND / OR: arrow-cast's string -> Boolean (compute_value.rs:72-73, :95-96), invalid spelling = NULL ---
+    ("utf8_and_casts_spellings", batch_bool_words, "value", "s and b",
+     (pa.bool_(), [True, True, False, False, None, None, False, None, None, False, None, False, False, False, None, None])),
+    ("utf8_or_casts_spellings", batch_bool_words, "value", "s or id > 100",
+     (pa.bool_(), [True, True, False, False, None, None, True, True, None, False, None, True, False, False, None, None])),
+    ("utf8_predicate_filter", batch_bool_words, "filter", "s and id > 0", [1, 6, 7, 11]),
+    ("utf8_literals_under_and", batch_bool_words, "value", "'yes' and 'off'", (pa.bool_(), [False])),
+    ("utf8_bad_literal_is_null", batch_bool_words, "value", "'maybe' or 'true'", (pa.bool_(), [None])),
+    ("utf8_literal_vs_column_length_mismatch", batch_bool_words, "error", "'true' and id > 0", 23),
     # ---- and / or take plain BooleanArrays: no scalar broadcast, result is never a scalar ---------------------
     ("and_with_literal_length_mismatch", batch_ints, "error", "i > 0 and true", 23),
     ("or_with_literal_length_mismatch", batch_ints, "error", "false or i > 0", 23),

@@ -168,3 +168,54 @@ def test_simple_sql_sample_queries_on_regenerated_dataset():
             np.testing.assert_array_equal(allp.value4.to_numpy(), np.float32(1.0) / idsq.astype(np.float32))
             np.testing.assert_array_equal(allp.value5.to_numpy(), idsq)
             assert list(allp.columns) == ["id", "value1", "id_plus_10", "value2", "value3", "value4", "value5"]
+
+
+def test_oracle_float16_vs_numpy():
+    """Float16 arithmetic (f32 operation rounded back to nearest-even f16), widening and total-order comparison
+    cross-checked against numpy's float16 on random bit patterns."""
+    rng = np.random.default_rng(16)
+    n = 20000
+    hb = rng.integers(0, 2**16, n).astype(np.uint16)
+    kb = rng.integers(0, 2**16, n).astype(np.uint16)
+    h, k = hb.view(np.float16), kb.view(np.float16)
+    rec = pa.RecordBatch.from_arrays([pa.array(h, pa.float16()), pa.array(k, pa.float16()),
+                                      pa.array(rng.standard_normal(n).astype(np.float32))], names=["h", "k", "f"])
+    al = empty_aliases(rec)
+    with np.errstate(all="ignore"):
+        for sql, want in (("h + k", h + k), ("h * k", h * k), ("h / k", h / k), ("h % k", np.fmod(h, k))):
+            got = O.compute_value(rec, al, parse_expr(sql))[0]
+            assert got.type == pa.float16()
+            g = got.to_numpy(zero_copy_only=False)
+            nan = np.isnan(want)
+            assert np.array_equal(np.isnan(g), nan), sql
+            assert np.array_equal(g.view(np.uint16)[~nan], want.view(np.uint16)[~nan]), sql
+        got = O.compute_value(rec, al, parse_expr("h + f"))[0]
+        want = h.astype(np.float32) + rec.column(2).to_numpy()
+        nan = np.isnan(want)
+        assert got.type == pa.float32()
+        assert np.array_equal(got.to_numpy().view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+    # total order: sign-magnitude key on the raw bits
+    key = lambda b: np.where(b & 0x8000, -(b & 0x7FFF).astype(np.int32) - 1, (b & 0x7FFF).astype(np.int32))
+    assert O.compute_value(rec, al, parse_expr("h < k"))[0].to_pylist() == (key(hb) < key(kb)).tolist()
+    assert O.compute_value(rec, al, parse_expr("h = k"))[0].to_pylist() == (hb == kb).tolist()
+
+
+def test_oracle_temporal_and_decimal_compares_vs_pyarrow():
+    import decimal
+    rng = np.random.default_rng(17)
+    n = 4000
+    mk = lambda typ, lo, hi: pa.array(rng.integers(lo, hi, n), pa.int32() if typ.bit_width == 32 else pa.int64()).view(typ)
+    dec = lambda: pa.array([decimal.Decimal(int(x) * 2**40 + int(y)) / 1000 for x, y in
+                            zip(rng.integers(-2**50, 2**50, n), rng.integers(0, 2**40, n))], pa.decimal128(38, 3))
+    cols = {"d1": mk(pa.date32(), -40000, 40000), "d2": mk(pa.date32(), -40000, 40000),
+            "t1": mk(pa.timestamp("us"), -2**50, 2**50), "t2": mk(pa.timestamp("us"), -2**50, 2**50),
+            "x1": dec(), "x2": dec()}
+    rec = pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols))
+    al = empty_aliases(rec)
+    for a, b in (("d1", "d2"), ("t1", "t2"), ("x1", "x2"), ("x1", "x1")):
+        for sym, fn in (("<", pc.less), ("<=", pc.less_equal), ("=", pc.equal), ("<>", pc.not_equal), (">", pc.greater), (">=", pc.greater_equal)):
+            got = O.compute_value(rec, al, parse_expr(f"{a} {sym} {b}"))[0]
+            assert got.to_pylist() == fn(cols[a], cols[b]).to_pylist(), (a, sym, b)
+    out = O.filter_record(rec, al, parse_expr("x1 < x2 and d1 >= d2"))
+    keep = pc.and_(pc.less(cols["x1"], cols["x2"]), pc.greater_equal(cols["d1"], cols["d2"]))
+    assert out.equals(rec.filter(keep))
