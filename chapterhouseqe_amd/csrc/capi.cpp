@@ -188,7 +188,8 @@ void lite_from_arrow(const ArrowDeviceArray* rec, const ArrowSchema* schema, con
         (ca->null_count > 0 && !ca->buffers[0])) { f |= GroupLite::GL_SCHEMA_DIFFERS; continue; }
     const uint8_t* validity = (const uint8_t*)ca->buffers[0];
     const uint8_t* values = (const uint8_t*)ca->buffers[1];
-    if (validity && ca->null_count != 0) f |= GroupLite::GL_NULLS;
+    if (validity && ca->null_count != 0) { f |= GroupLite::GL_NULLS; lite.validity[b * nc + i] = validity; }
+    lite.offset[b * nc + i] = ca->offset;
     if (c0.type == T_UTF8) {
       const uint8_t* data = ca->n_buffers > 2 ? (const uint8_t*)ca->buffers[2] : nullptr;
       if (!data) f |= GroupLite::GL_NO_UTF8_DATA;

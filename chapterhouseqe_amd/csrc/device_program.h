@@ -127,7 +127,8 @@ struct ProgramBlock {
   int32_t n_instr;
   int32_t n_refs;
   int32_t fast_kind;
-  int32_t pad;
+  int32_t group_bits_at;   // = FilterParams::group_bits_at (kept here so that the interpreter reads it from the kernel
+                           // arguments where it is used instead of carrying it -- and a second row pointer -- in SGPRs)
   Instr prog[MAX_INSTR];
   ColRef refs[MAX_REFS];
   ConstStr strs[MAX_CONST_STR];
@@ -248,6 +249,27 @@ struct BitCompactGroupParams {
   int32_t pad;
   uint32_t* out_bits;        // zero-initialised
   u64* zero_count;
+};
+
+// typed_ops.hip: operations of the reference's type coverage that are not device-program instructions; each writes a
+// temporary Boolean column (value bitmap + validity bitmap, bit i = row i) that the program then reads like any other.
+struct Cmp128Params {        // Decimal128 (i128) comparison of two columns, arrow-ord cmp::* on the native values
+  const void* a; const void* b;            // values at row 0 (16 bytes per row, any 4-byte alignment)
+  const void* a_validity; const void* b_validity;   // bitmaps or null
+  int64_t a_validity_offset, b_validity_offset;
+  int64_t nrows;
+  int32_t op;                // OP_EQ .. OP_GE
+  int32_t pad;
+  u64* out_bits; u64* out_validity;        // (nrows + 63) / 64 words each
+  u64* null_count;           // zero-initialised
+};
+struct Utf8ToBoolParams {    // arrow-cast cast_utf8_to_boolean: trimmed, case-folded spelling -> true / false / NULL
+  const int32_t* offsets;    // at row 0
+  const uint8_t* data;
+  const void* validity; int64_t validity_offset;
+  int64_t nrows;
+  u64* out_bits; u64* out_validity;
+  u64* null_count;
 };
 
 struct SplitBoundsParams {   // split_bounds_kernel: out[i] = number of selected rows before input row starts[i]

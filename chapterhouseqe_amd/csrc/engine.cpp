@@ -483,6 +483,8 @@ void GroupLite::set(size_t b, const Batch& r, const Batch& first, int device) {
     if (c.type == T_UTF8 && c.data == nullptr) f |= GL_NO_UTF8_DATA;
     values0[b * ncols + i] = c.type == T_BOOL ? c.values : (const uint8_t*)c.values0();
     data[b * ncols + i] = c.data;
+    validity[b * ncols + i] = (c.validity && c.null_count != 0) ? c.validity : nullptr;
+    offset[b * ncols + i] = c.offset;
   }
   flags[b] = f;
 }
@@ -491,7 +493,7 @@ std::vector<PlanColumn> plan_columns(const Batch& b, const chq_table_aliases* al
   std::vector<PlanColumn> out;
   for (size_t i = 0; i < b.cols.size(); ++i) {
     PlanColumn p;
-    p.name = b.cols[i].name; p.type = b.cols[i].type;
+    p.name = b.cols[i].name; p.type = b.cols[i].type; p.format = b.cols[i].format; p.width = b.cols[i].width;
     p.has_nulls = b.cols[i].validity && b.cols[i].null_count != 0;
     // without an explicit table_aliases argument every column has an (empty) alias list
     p.alias_entry_present = aliases ? (int)i < aliases->n_columns : true;
@@ -740,7 +742,8 @@ void fill_refs(ProgramBlock& pb, const Lowered& lw, const Batch& rec, const std:
     r.data = c.data;
     r.validity_bit_offset = c.offset;
     r.bool_bit_offset = c.offset;
-    r.type = c.type;
+    // a temporal column inside a program is one side of a same-type comparison: its values ARE Int32 / Int64 (plan.cpp)
+    r.type = c.type == T_FIXED_OPAQUE ? (c.width == 4 ? T_I32 : T_I64) : c.type;
     pb.refs[i] = r;
   }
   for (size_t i = 0; i < lw.strs.size(); ++i) { pb.strs[i].bytes = (const uint8_t*)str_bufs[i]->ptr; pb.strs[i].len = (int64_t)lw.strs[i].size(); }
@@ -772,7 +775,8 @@ int pick_tile_kind(const Context& ctx, const Lowered& lw, int64_t rows) {
   return rows >= (1 << 18) ? 0 : 1;
 }
 
-bool stashable(const Column& c) { return c.type != T_BOOL && c.type != T_UTF8 && c.width > 0 && c.width <= 4; }
+// (a Float16 operand reaches the stash widened to f32: not the column's bytes)
+bool stashable(const Column& c) { return c.type != T_BOOL && c.type != T_UTF8 && c.type != T_F16 && c.width > 0 && c.width <= 4; }
 
 // Up to `slots` narrow predicate input columns stay on chip between the predicate and copy phases (device_program.h:
 // FilterParams::stash_refs); they move to the end of the launch's column order, slot k <-> the k-th of them.
@@ -833,8 +837,59 @@ void materialize_node(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols,
   te.nodes[node] = repl;
 }
 
+// Decimal128 comparisons and Utf8 -> Boolean casts are not device-program instructions (plan.hpp: Node): their own
+// kernels (typed_ops.hip) write a temporary Boolean column, which replaces the node like any other materialisation.
+bool is_typed_op(const TypedExpr& te, int node) {
+  const Node& n = te.nodes[node];
+  return (n.kind == Node::CMP && n.from == T_FIXED_OPAQUE) || (n.kind == Node::TOBOOL && n.from == T_UTF8);
+}
+void materialize_typed_op(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te, int node) {
+  const Node n = te.nodes[node];
+  const int64_t nrows = work.nrows;
+  const size_t words = (size_t)((nrows + 63) / 64) + 1;
+  auto bits = make_device_buffer(words * 8, ctx.device), valid = make_device_buffer(words * 8, ctx.device);
+  auto count = make_device_buffer(16, ctx.device);
+  check_hip(hipMemsetAsync(count->ptr, 0, 16, ctx.stream), "memset");
+  if (n.kind == Node::CMP) {
+    const Column& a = work.cols[(size_t)te.nodes[n.l].col];
+    const Column& b = work.cols[(size_t)te.nodes[n.r].col];
+    Cmp128Params p{};
+    p.a = a.values0(); p.b = b.values0();
+    p.a_validity = (a.validity && a.null_count != 0) ? a.validity : nullptr; p.a_validity_offset = a.offset;
+    p.b_validity = (b.validity && b.null_count != 0) ? b.validity : nullptr; p.b_validity_offset = b.offset;
+    p.nrows = nrows; p.op = n.op;
+    p.out_bits = (u64*)bits->ptr; p.out_validity = (u64*)valid->ptr; p.null_count = (u64*)count->ptr;
+    if (nrows > 0) check_hip(launch_cmp128(p, ctx.stream), "launch cmp128_kernel");
+  } else {
+    const Column& c = work.cols[(size_t)te.nodes[n.l].col];
+    Utf8ToBoolParams p{};
+    p.offsets = (const int32_t*)c.values0(); p.data = c.data;
+    p.validity = (c.validity && c.null_count != 0) ? c.validity : nullptr; p.validity_offset = c.offset;
+    p.nrows = nrows;
+    p.out_bits = (u64*)bits->ptr; p.out_validity = (u64*)valid->ptr; p.null_count = (u64*)count->ptr;
+    if (nrows > 0) check_hip(launch_utf8_to_bool(p, ctx.stream), "launch utf8_to_bool_kernel");
+  }
+  u64 nulls = 0;
+  check_hip(hipMemcpyAsync(&nulls, count->ptr, 8, hipMemcpyDeviceToHost, ctx.stream), "read null count");
+  check_hip(hipStreamSynchronize(ctx.stream), "sync");
+  Column c;
+  c.name = "__chq_tmp_" + std::to_string(work.cols.size());
+  c.format = "b"; c.type = T_BOOL; c.width = 0; c.length = nrows; c.null_count = (int64_t)nulls; c.nullable = nulls != 0;
+  c.values = (const uint8_t*)bits->ptr; c.validity = nulls ? (const uint8_t*)valid->ptr : nullptr;
+  c.owned = {bits, valid};
+  PlanColumn pc;
+  pc.name = c.name; pc.type = T_BOOL; pc.has_nulls = nulls != 0; pc.alias_entry_present = true; pc.format = "b";
+  Node repl{};
+  repl.kind = Node::COL; repl.type = T_BOOL; repl.is_scalar = false; repl.len1 = false;
+  repl.col = (int)work.cols.size(); repl.ref_order = n.ref_order;
+  work.cols.push_back(std::move(c));
+  wcols.push_back(std::move(pc));
+  te.nodes[node] = repl;
+}
+
 void fit_subtree(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te, int node, bool strict, bool is_root) {
   if (is_leaf_node(te.nodes[node])) return;
+  if (is_typed_op(te, node)) { materialize_typed_op(ctx, work, wcols, te, node); return; }
   const int l = te.nodes[node].l, r = te.nodes[node].r;
   if (l >= 0) fit_subtree(ctx, work, wcols, te, l, strict, false);
   if (r >= 0) fit_subtree(ctx, work, wcols, te, r, strict, false);
@@ -891,6 +946,10 @@ Column empty_like(const Column& c) {
 Batch filter_record(Context& ctx, const Batch& rec, const std::vector<PlanColumn>& pcols, const Expr& expr, SplitRequest* split) {
   const int64_t nrows = rec.nrows;
   TypedExpr te = typed(ctx, rec, pcols, expr);
+  if (te.nodes[(size_t)te.root].kind == Node::CONST && te.nodes[(size_t)te.root].cval.null) {
+    Scalar& v = te.nodes[(size_t)te.root].cval;   // a NULL mask slot drops its row (prep_null_mask_filter)
+    v.null = false; v.bits = 0;
+  }
   const Node& root = te.at(te.root);
   if (root.type != T_BOOL) {   // RU/filter_record.rs:27-35
     // the reference has already evaluated the expression at this point: data-dependent errors come first
@@ -2158,13 +2217,11 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
   std::vector<BitCol> bit_cols;
   if (need_bits) {
     if (wpb == 0) return other_path();   // ragged group: joined on the device
-    need_batches();   // (the bitmaps' addresses and offsets are read from the batches)
-    pool_ranges(nb, 2048, [&](size_t b0, size_t b1) {
-      for (size_t b = b0; b < b1; ++b) {
-        if (!(lite->flags[b] & GroupLite::GL_NULLS)) continue;
-        for (size_t i = 0; i < ncols; ++i) if (recs[b].cols[i].validity && recs[b].cols[i].null_count != 0) col_nulls[i] = 1;
-      }
-    });
+    // (the bitmaps' addresses and offsets come from the flat per-batch arrays: no Batch objects, as in the null-free case)
+    for (size_t b = 0; b < nb; ++b) {
+      if (!(lite->flags[b] & GroupLite::GL_NULLS)) continue;
+      for (size_t i = 0; i < ncols; ++i) if (lite->validity[b * ncols + i]) col_nulls[i] = 1;
+    }
     for (size_t i = 0; i < ncols; ++i) {
       if (col_nulls[i]) { proto.cols[i].validity = (const uint8_t*)proto.cols[i].values; proto.cols[i].null_count = 1; }   // (never read: a marker)
       else { proto.cols[i].validity = nullptr; proto.cols[i].null_count = 0; }
@@ -2206,13 +2263,12 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
         for (size_t k = 0; k < nout; ++k) *w++ = (u64)(uintptr_t)in_ptr[b][launch_cols[k]];
         for (size_t k = 0; k < nu; ++k) { *w++ = (u64)(uintptr_t)in_ptr[b][fold_utf8[k]]; *w++ = utf8_data(b, k); }
         if (need_bits) {
-          const Batch& rb = recs[b];
-          auto vbits = [&](size_t i) -> u64 { const Column& c = rb.cols[i]; return (c.validity && c.null_count != 0) ? (u64)(uintptr_t)c.validity : 0; };
-          for (size_t k = 0; k < nrefs; ++k) *w++ = vbits((size_t)lw.refs[k]);
-          for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)rb.cols[(size_t)lw.refs[k]].offset;
+          const size_t at = b * ncols;
+          for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)(uintptr_t)lite->validity[at + (size_t)lw.refs[k]];
+          for (size_t k = 0; k < nrefs; ++k) *w++ = (u64)lite->offset[at + (size_t)lw.refs[k]];
           for (const BitCol& q : bit_cols) {
-            *w++ = q.validity ? vbits((size_t)q.col) : (u64)(uintptr_t)rb.cols[(size_t)q.col].values;
-            *w++ = (u64)rb.cols[(size_t)q.col].offset;
+            *w++ = (u64)(uintptr_t)(q.validity ? lite->validity[at + (size_t)q.col] : lite->values0[at + (size_t)q.col]);   // (a Boolean column's values0 is its bitmap)
+            *w++ = (u64)lite->offset[at + (size_t)q.col];
           }
         }
         continue;
@@ -2245,7 +2301,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
   if (need_bits) {
     g_sel = make_device_buffer((size_t)(nslots + 8) * 8, ctx.device);
     g_base = make_device_buffer((size_t)(nslots + 8) * 8, ctx.device);
-    p.sel_mask = (u64*)g_sel->ptr; p.grp_base = (u64*)g_base->ptr; p.group_bits_at = (int32_t)bits_at;
+    p.sel_mask = (u64*)g_sel->ptr; p.grp_base = (u64*)g_base->ptr; p.group_bits_at = (int32_t)bits_at; p.pb.group_bits_at = (int32_t)bits_at;
   }
   for (size_t k = 0; k < nu; ++k) {   // Utf8 columns: joined offsets (from 0) and bytes, capacity = the input bytes
     const size_t i = (size_t)fold_utf8[k];
@@ -2418,10 +2474,11 @@ Column scalar_column(Context& ctx, const Scalar& s, const std::string& name) {
     if (!s.str.empty()) check_hip(hipMemcpy(db->ptr, s.str.data(), s.str.size(), hipMemcpyHostToDevice), "memcpy");
     o.values = (const uint8_t*)ob->ptr; o.data = (const uint8_t*)db->ptr; o.owned = {ob, db};
   } else {
-    uint64_t bits = s.bits;
+    uint64_t bits[2] = {s.null ? 0 : s.bits, 0};   // second word: the validity bitmap of a NULL value
     auto vb = make_device_buffer(16, ctx.device);
-    check_hip(hipMemcpy(vb->ptr, &bits, 8, hipMemcpyHostToDevice), "memcpy");
+    check_hip(hipMemcpy(vb->ptr, bits, 16, hipMemcpyHostToDevice), "memcpy");
     o.values = (const uint8_t*)vb->ptr; o.owned = {vb};
+    if (s.null) { o.validity = (const uint8_t*)vb->ptr + 8; o.null_count = 1; o.nullable = true; }
   }
   return o;
 }
@@ -2434,7 +2491,8 @@ struct ProjItem {   // one computed output of a launch
 bool subtree_can_null(const TypedExpr& t, int ni, const std::vector<PlanColumn>& cols) {
   const Node& n = t.at(ni);
   if (n.kind == Node::COL) return cols[n.col].has_nulls;
-  bool r = false;
+  if (n.kind == Node::CONST) return n.cval.null;
+  bool r = n.kind == Node::TOBOOL && n.from == T_UTF8;   // a bad spelling is NULL
   if (n.l >= 0) r |= subtree_can_null(t, n.l, cols);
   if (n.r >= 0) r |= subtree_can_null(t, n.r, cols);
   return r;
@@ -2454,7 +2512,7 @@ std::vector<Column> evaluate_dense(Context& ctx, const Batch& rec, const std::ve
     const Node& root = exprs[k]->at(exprs[k]->root);
     Column& o = results[k];
     o.type = root.type; o.format = format_of(root.type); o.width = dtype_width(root.type); o.length = nrows;
-    if (root.type == T_UTF8 || root.type == T_FIXED_OPAQUE || root.type == T_F16)
+    if (root.type == T_UTF8 || root.type == T_FIXED_OPAQUE)
       throw ChqError{CHQ_ERR_NOT_SUPPORTED, std::string("expression result of type ") + dtype_name(root.type) + " is outside this build's scope"};
   }
   if (nrows == 0) {
@@ -2928,6 +2986,7 @@ std::string describe_plan(const ArrowSchema* schema, const chq_table_aliases* al
     int width = 0;
     p.name = cs->name ? cs->name : "";
     parse_format(cs->format, &p.type, &width);
+    p.format = cs->format ? cs->format : ""; p.width = width;
     p.has_nulls = (cs->flags & ARROW_FLAG_NULLABLE) != 0;
     p.alias_entry_present = aliases ? (int)i < aliases->n_columns : true;
     if (aliases && (int)i < aliases->n_columns)
@@ -2950,7 +3009,14 @@ std::string describe_plan(const ArrowSchema* schema, const chq_table_aliases* al
   }
   if (root.kind == Node::COL) { out += "column " + std::to_string(root.col) + "\n"; return out; }
   Lowered lw;
-  lower_expr(te, te.root, cols, lw);
+  try {
+    lower_expr(te, te.root, cols, lw);
+  } catch (const ChqError& e) {
+    if (e.code != CHQ_INTERNAL_PROGRAM_LIMIT) throw;
+    // valid, but more than one device program: the engine evaluates sub-trees into temporary columns first (fit_to_device)
+    out += "split " + e.msg + "\n";
+    return out;
+  }
   out += "program wide=" + std::to_string((int)lw.wide) + " num_temps=" + std::to_string(lw.num_temps) + " refs=";
   for (size_t i = 0; i < lw.refs.size(); ++i) out += (i ? "," : "") + std::to_string(lw.refs[i]);
   out += "\n";

@@ -23,6 +23,8 @@ hipError_t launch_filter_project(const FusedParams& p, int tile_kind, int grid, 
 hipError_t launch_project(const ProjectParams& p, int tile_kind, bool partial, int grid, hipStream_t stream);
 hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t stream);
 hipError_t launch_bit_compact_group(const BitCompactGroupParams& p, int grid, hipStream_t stream);
+hipError_t launch_cmp128(const Cmp128Params& p, hipStream_t stream);
+hipError_t launch_utf8_to_bool(const Utf8ToBoolParams& p, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);
@@ -201,9 +203,11 @@ struct GroupLite {
   std::vector<int64_t> rows;               // [nb]
   std::vector<const uint8_t*> values0;     // [nb * ncols] Column::values0() (Boolean: the bitmap)
   std::vector<const uint8_t*> data;        // [nb * ncols] Utf8 bytes
+  std::vector<const uint8_t*> validity;    // [nb * ncols] validity bitmap, null when the column has no nulls in that batch
+  std::vector<int64_t> offset;             // [nb * ncols] Arrow slice offset: bit position of row 0 in the bitmaps
   std::vector<uint8_t> flags;              // [nb] GL_*
   enum : uint8_t { GL_NULLS = 1, GL_NO_UTF8_DATA = 2, GL_SCHEMA_DIFFERS = 4, GL_ON_DEVICE = 8, GL_SHORT = 16 };
-  void resize(size_t nb, size_t nc) { ncols = nc; rows.assign(nb, 0); values0.assign(nb * nc, nullptr); data.assign(nb * nc, nullptr); flags.assign(nb, 0); }
+  void resize(size_t nb, size_t nc) { ncols = nc; rows.assign(nb, 0); values0.assign(nb * nc, nullptr); data.assign(nb * nc, nullptr); validity.assign(nb * nc, nullptr); offset.assign(nb * nc, 0); flags.assign(nb, 0); }
   void set(size_t b, const Batch& r, const Batch& first, int device);
 };
 // The one-launch result of a group call before it is cut into per-batch Arrow structs: dense output buffers every batch's

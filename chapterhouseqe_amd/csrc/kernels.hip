@@ -18,6 +18,7 @@
 // successors need it.  Tiles are handed out by an atomic ticket, so the scan can never wait on a
 // workgroup that has not started (no co-residency assumption).
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <type_traits>
 #include "device_program.h"
@@ -222,6 +223,21 @@ __device__ __forceinline__ void report_error(u64* err, uint32_t ref_order, int64
   atomicMax(err, ~(((u64)ref_order << 56) | ((u64)row << 8) | (u64)code));
 }
 
+// Float16 values live in the interpreter as the f32 with the same value.  The widening is exact, and NaNs keep their
+// payload WITHOUT being quieted (the hardware conversion would set the quiet bit), so the embedding is one-to-one and
+// monotone under IEEE totalOrder: the f32 comparison code then gives f16's total order and bitwise equality unchanged.
+// A real cast to Float32 / Float64 (arrow-cast through half::f16::to_f32) quiets the NaN: Interp::convert does that.
+__device__ __forceinline__ uint32_t f16_widen(uint32_t h) {
+  uint32_t w = __float_as_uint(__half2float(__ushort_as_half((unsigned short)h)));
+  if ((h & 0x7fffu) > 0x7c00u) w = ((h & 0x8000u) << 16) | 0x7f800000u | ((h & 0x3ffu) << 13);
+  return w;
+}
+// arrow's f16 arithmetic is half's: from_f32(to_f32(a) OP to_f32(b)), round to nearest even
+__device__ __forceinline__ uint32_t f16_round(uint32_t f) {
+  return __float_as_uint(__half2float(__float2half_rn(__uint_as_float(f))));
+}
+__device__ __forceinline__ uint16_t f16_bits(uint32_t f) { return __half_as_ushort(__float2half_rn(__uint_as_float(f))); }
+
 // value classes the interpreter computes in
 enum VClass { C_I32, C_U32, C_I64, C_U64, C_F32, C_F64, C_BOOL, C_NONE };
 __device__ __forceinline__ int vclass(int t) {
@@ -232,6 +248,14 @@ __device__ __forceinline__ int vclass(int t) {
     case T_F32: return C_F32; case T_F64: return C_F64; case T_BOOL: return C_BOOL;
     default: return C_NONE;
   }
+}
+// Float16 is computed in f32 (see f16_widen) and rounded back to f16 after every operation -- in the WIDE kernel
+// instantiations only (plan.cpp marks Float16 programs wide): the 1024-thread kernels run at their 128-VGPR limit, and
+// even an extra case label in their type switches brought spills back
+template <bool WIDE>
+__device__ __forceinline__ int vclass_of(int t) {
+  if constexpr (WIDE) { if (t == T_F16) return C_F32; }
+  return vclass(t);
 }
 __device__ __forceinline__ void int_range(int t, int64_t& lo, int64_t& hi) {
   switch (t) {
@@ -273,8 +297,8 @@ struct Interp {
   int stash_ref[NSA];
   int n_stash = 0;
   const u64* ptr_row = nullptr;   // batch-group launch: value pointer of column-ref k is ptr_row[k] (PARTIAL only)
-  const u64* ptr_bits = nullptr;  // ... and, when the group carries bitmaps: ptr_bits[k] = validity bitmap of column-ref k in this
-  int n_refs_bits = 0;            // wave's batch (0: none), ptr_bits[n_refs_bits + k] = bit position of the batch's row 0 in its bitmaps
+  // ... and, when the group carries bitmaps (ProgramBlock::group_bits_at = B > 0): ptr_row[B - 1 + k] = validity bitmap of
+  // column-ref k in this wave's batch (0: none), ptr_row[B - 1 + n_refs + k] = bit position of the batch's row 0 in its bitmaps
 
   __device__ __forceinline__ void set_rows(int64_t tile_start, int64_t nrows_, int lane_, int wv_) {
     lane = lane_; wv = wv_; nrows = nrows_;
@@ -326,6 +350,21 @@ struct Interp {
   template <bool FULL>
   __device__ __forceinline__ void fetch_values(const ColRef& cr, const void* values, uint32_t (&l)[R], uint32_t (&h)[RH]) {
     struct { int type; const void* values; } c{cr.type, values};
+    if constexpr (WIDE) {
+      if (c.type == T_F16) {
+        if constexpr (FULL) {
+          const uint16_t* p = (const uint16_t*)c.values + w0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = f16_widen(p[j * 64 + lane]);
+        } else {
+          const int ol = opaque_lane(lane);
+          const auto r = wave_rows_rsrc(c.values, w0, 2, nact);
+#pragma unroll
+          for (int j = 0; j < R; ++j) l[j] = f16_widen(buf_load<uint16_t>(r, j * 64 + ol));
+        }
+        return;
+      }
+    }
     // FULL: the wave's 64*R rows are all inside the batch -> element j*64+lane, immediate offsets off an SGPR base.
     // Otherwise (nact > 0 rows): range-checked buffer loads, rows past the end read as 0.
     if constexpr (FULL) {
@@ -342,6 +381,7 @@ struct Interp {
         case T_U16: { const uint16_t* p = (const uint16_t*)c.values + w0;
 #pragma unroll
           for (int j = 0; j < R; ++j) l[j] = p[j * 64 + lane]; } break;
+
         case T_I32: case T_U32: case T_F32: { const uint32_t* p = (const uint32_t*)c.values + w0;
 #pragma unroll
           for (int j = 0; j < R; ++j) l[j] = p[j * 64 + lane]; } break;
@@ -367,6 +407,7 @@ struct Interp {
         case T_U16: { const auto r = wave_rows_rsrc(c.values, w0, 2, nact);
 #pragma unroll
           for (int j = 0; j < R; ++j) l[j] = buf_load<uint16_t>(r, j * 64 + ol); } break;
+
         case T_I32: case T_U32: case T_F32: { const auto r = wave_rows_rsrc(c.values, w0, 4, nact);
 #pragma unroll
           for (int j = 0; j < R; ++j) l[j] = buf_load<uint32_t>(r, j * 64 + ol); } break;
@@ -380,25 +421,22 @@ struct Interp {
     }
   }
 
-  __device__ __forceinline__ void fetch_col(const ColRef& c, int ref_idx, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
+  __device__ __forceinline__ void fetch_col(const ProgramBlock& pb, const ColRef& c, int ref_idx, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
     b = 0;
     if constexpr (!PARTIAL) {
       if (c.type == T_BOOL) b = fetch_flags(c.values, c.bool_bit_offset);
       else fetch_values<true>(c, c.values, l, h);
     } else {
       const void* vals = ptr_row ? (const void*)ptr_row[ref_idx] : c.values;
-      if (ptr_bits) {   // batch-group launch with bitmaps: this wave's batch has its own (see FilterParams::group_bits_at)
-        const int64_t bitoff = (int64_t)ptr_bits[n_refs_bits + ref_idx];
-#pragma unroll
-        for (int j = 0; j < R; ++j) l[j] = 0;
-#pragma unroll
-        for (int j = 0; j < RH; ++j) h[j] = 0;
-        if (c.type == T_BOOL) { if (nact > 0) b = fetch_flags(vals, bitoff); }   // (a Boolean column's value pointer is its bitmap)
-        else if (nact == 64 * R) fetch_values<true>(c, vals, l, h);
-        else if (nact > 0) fetch_values<false>(c, vals, l, h);
-        const void* vb = (const void*)ptr_bits[ref_idx];
-        v = (vb && nact > 0) ? (fetch_flags(vb, bitoff) & actv) : actv;
-        return;
+      // a batch-group launch with bitmaps (ProgramBlock::group_bits_at): this wave's batch has its own validity bitmap and
+      // bit position of row 0.  Only the addresses differ -- ONE copy of the loads below serves both kinds of launch (a
+      // second inlined copy of the type switch brought spills back into the 1024-thread kernels)
+      const void* vb = c.validity;
+      int64_t voff = c.validity_bit_offset, boff = c.bool_bit_offset;
+      if (ptr_row && pb.group_bits_at) {
+        const u64* ptr_bits = ptr_row + (pb.group_bits_at - 1);
+        vb = (const void*)ptr_bits[ref_idx];
+        voff = boff = (int64_t)ptr_bits[pb.n_refs + ref_idx];
       }
       if (nact == 64 * R && c.type != T_BOOL) {
         // a complete wave inside an incomplete tile (or a batch-group launch): same code as the FULL instantiation
@@ -409,10 +447,12 @@ struct Interp {
 #pragma unroll
         for (int j = 0; j < RH; ++j) h[j] = 0;
         if (nact > 0) {
-          if (c.type == T_BOOL) b = fetch_flags(vals, c.bool_bit_offset);
+          if (c.type == T_BOOL) b = fetch_flags(vals, boff);   // (a Boolean column's value pointer is its bitmap)
           else fetch_values<false>(c, vals, l, h);
         }
       }
+      v = (vb && nact > 0) ? (fetch_flags(vb, voff) & actv) : actv;   // (a wave past the end of its batch reads nothing)
+      return;
     }
     v = c.validity ? (fetch_flags(c.validity, c.validity_bit_offset) & actv) : actv;
   }
@@ -420,7 +460,13 @@ struct Interp {
   // convert values from the class of `from_t` to the class of `to_t` in place: exactly the widenings the
   // coercion table RU/compute_value.rs:350-431 can request, plus numeric -> Boolean (value != 0)
   __device__ __forceinline__ void convert(int from_t, int to_t, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b) {
-    const int from = vclass(from_t), to = vclass(to_t);
+    const int from = vclass_of<WIDE>(from_t), to = vclass_of<WIDE>(to_t);
+    if constexpr (WIDE) {
+      if (from_t == T_F16 && (to_t == T_F32 || to_t == T_F64)) {   // half::f16::to_f32 quiets a signalling NaN
+#pragma unroll
+        for (int j = 0; j < R; ++j) if ((l[j] & 0x7fffffffu) > 0x7f800000u) l[j] |= 0x00400000u;
+      }
+    }
     if (from == to || from == C_BOOL || from == C_NONE) return;
     // (every wave-uniform choice is made OUTSIDE the slot loops: left inside, the compiler evaluates both sides for
     // every slot and selects with a v_cndmask)
@@ -480,7 +526,7 @@ struct Interp {
   __device__ __forceinline__ void arith(int op, int t, bool rev, bool bconst, const uint32_t (&bl_)[R], const uint32_t (&bh_)[RH], u64* err, uint32_t ref_order) {
 #define bl(j) bl_[j]
 #define bh(j) bh_[j]
-    const int cls = vclass(t);
+    const int cls = vclass_of<WIDE>(t);
     // x / 2^k and x % 2^k with a literal divisor (`id % 2 = 0` is in the reference's sample queries): shifts and masks
     // instead of the ~40-instruction software division; cannot fail (divisor > 0), truncates toward zero like arrow's
     // div / rem (sign of the dividend)
@@ -579,6 +625,12 @@ struct Interp {
         default: if (rev) F32_LOOP(y, x, fmodf(a, b)) else F32_LOOP(x, y, fmodf(a, b)) break;
       }
 #undef F32_LOOP
+      if constexpr (WIDE) {
+        if (t == T_F16) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) lo[j] = f16_round(lo[j]);
+        }
+      }
     } else if constexpr (WIDE) {
       // 64-bit classes: as above, the operator and the operand order are chosen OUTSIDE the slot loops (a switch inside the
       // unrolled loop made the compiler index the register arrays dynamically, i.e. keep them in scratch memory)
@@ -640,7 +692,7 @@ struct Interp {
 
   // ---- comparisons: arrow-ord cmp::*; floats by IEEE totalOrder ------------------------------------
   __device__ __forceinline__ void compare(int op, int t, bool rev, bool bconst, const uint32_t (&bl)[R], const uint32_t (&bh)[RH], uint32_t bb) {
-    const int cls = vclass(t);
+    const int cls = vclass_of<WIDE>(t);
     if (cls == C_BOOL) {
       const uint32_t a = rev ? bb : bitsv, b = rev ? bitsv : bb;
       const uint32_t ltv = ~a & b, eqv = ~(a ^ b);
@@ -917,14 +969,14 @@ struct Interp {
       const bool bconst = in.src_kind == SRC_CONST;
       const uint32_t cl = (uint32_t)in.imm, ch = (uint32_t)(in.imm >> 32);
       if (in.op == OP_LOAD && in.src_kind == SRC_COL) {   // straight into the accumulator
-        fetch_col(pb.refs[in.src_idx], in.src_idx, lo, hi, bitsv, validv);
+        fetch_col(pb, pb.refs[in.src_idx], in.src_idx, lo, hi, bitsv, validv);
         stash_put((int)in.src_idx, lo);
         convert(in.src_type, in.type, lo, hi, bitsv);
         acc_type = in.type;
         continue;
       }
       if (in.src_kind == SRC_COL) {
-        fetch_col(pb.refs[in.src_idx], in.src_idx, bl, bh, bb, bv);
+        fetch_col(pb, pb.refs[in.src_idx], in.src_idx, bl, bh, bb, bv);
         stash_put((int)in.src_idx, bl);
         if (in.op != OP_STRCMP) convert(in.src_type, in.type, bl, bh, bb);
       } else if (bconst) {   // all slots hold the same value: after unrolling the compiler keeps one copy
@@ -1081,7 +1133,6 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
           const u64* brow = p.group + (int64_t)b * p.group_stride;
           nr = uniform64((int64_t)brow[0]);
           it.ptr_row = brow + 1;
-          if (p.group_bits_at) { it.ptr_bits = brow + p.group_bits_at; it.n_refs_bits = p.pb.n_refs; }
           row0 = ((int64_t)lw - wv) * (64 * R);   // set_rows adds wv * 64 R back
         } else { nr = 0; row0 = 0; it.ptr_row = p.group; }
       } else if (p.group) {   // batch-group launch: the tile's rows and column pointers come from the tile table
@@ -1104,13 +1155,20 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     if (p.sel_mask) {
       // single batch: one word per 64 rows of the batch; wave-packed group: one word per slot of every wave slot
       int64_t gidx = it.w0 >> 6;
-      bool slots = false;
-      if constexpr (PARTIAL) { if (p.group_wpb > 0) { gidx = (tile * NW + wv) * R; slots = true; } }
+      int nst = R;   // slots of this wave that exist: all of them in a complete tile and in a wave-packed group (whose table has a word per slot)
+      if constexpr (PARTIAL) {
+        if (p.group_wpb > 0) gidx = (int64_t)(((uint32_t)tile * NW + (uint32_t)wv) * R);   // (slot indices fit 32 bits: at most 2^31 / 64 slots)
+        else nst = (it.nact + 63) >> 6;
+      }
+      // lane j keeps slot j's word: one store of R consecutive words per wave (and each ballot's SGPR pair is dead
+      // after two selects -- written one by one from lane 0 the R masks were all live at once)
+      u64 mine = 0;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const u64 m = __ballot((selv >> j) & 1);
-        if (lane == 0 && (slots || it.w0 + 64 * j < p.nrows)) p.sel_mask[gidx + j] = m;
+        if (lane == j) mine = m;
       }
+      if (lane < nst) p.sel_mask[gidx + lane] = mine;
     }
     unsigned cnt = __popc(selv);
 #pragma unroll
@@ -1230,14 +1288,19 @@ __global__ __launch_bounds__(BLOCK) void filter_fused_kernel(const FilterParams 
     if (p.grp_base) {
       u64 run = off0;
       int64_t gidx = w0 >> 6;
-      bool slots = false;
-      if constexpr (PARTIAL) { if (p.group_wpb > 0) { gidx = (tile * NW + wv) * R; slots = true; } }
+      int nst = R;
+      if constexpr (PARTIAL) {
+        if (p.group_wpb > 0) gidx = (int64_t)(((uint32_t)tile * NW + (uint32_t)wv) * R);
+        else nst = (nact + 63) >> 6;
+      }
+      u64 mine = 0;   // lane j keeps slot j's base: one store of R consecutive words per wave
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         const u64 m = __ballot((selv >> j) & 1);
-        if (lane == 0 && (slots || w0 + 64 * j < p.nrows)) p.grp_base[gidx + j] = run;
+        if (lane == j) mine = run;
         run += __popcll(m);
       }
+      if (lane < nst) p.grp_base[gidx + lane] = mine;
     }
     // Utf8 columns: the offsets of the first step are requested before the fixed-width copies, whose loads they join
     constexpr int CH = 4;                                   // 64-row groups per step (8 spill at the 128-VGPR budget of the 1024-thread tile: 3.0 ms vs 2.2 ms)
@@ -1604,6 +1667,9 @@ __global__ __launch_bounds__(BLOCK) void filter_project_kernel(const FusedParams
       const u64 m = __ballot(sel);                                                                     \
       if (sel) dst[run + lane_rank(m)] = (EXPR);                                                       \
       run += __popcll(m); } }
+        if constexpr (WIDE) {
+          if (acc_type == T_F16) { CSTORE(uint16_t, f16_bits(s.lo[j])) return; }
+        }
         switch (acc_type) {
           case T_I8: case T_U8: CSTORE(uint8_t, (uint8_t)s.lo[j]) break;
           case T_I16: case T_U16: CSTORE(uint16_t, (uint16_t)s.lo[j]) break;
@@ -1651,10 +1717,14 @@ __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
           if (lane == 0 && s.w0 + 64 * j < p.nrows) ((u64*)po.values)[(s.w0 >> 6) + j] = m;
         }
       } else {
-        switch (acc_type) {
+        bool stored = false;
 #define STORE_COL(TY, EXPR)                                                              \
   { TY* dst = (TY*)po.values + s.w0;                                                     \
     _Pragma("unroll") for (int j = 0; j < R; ++j) if ((s.actv >> j) & 1) dst[j * 64 + lane] = (EXPR); }
+        if constexpr (WIDE) {
+          if (acc_type == T_F16) { STORE_COL(uint16_t, f16_bits(s.lo[j])) stored = true; }
+        }
+        if (!stored) switch (acc_type) {
           case T_I8: case T_U8: STORE_COL(uint8_t, (uint8_t)s.lo[j]) break;
           case T_I16: case T_U16: STORE_COL(uint16_t, (uint16_t)s.lo[j]) break;
           case T_I32: case T_U32: case T_F32: STORE_COL(uint32_t, s.lo[j]) break;
@@ -1691,6 +1761,7 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactPara
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t nchunks = (p.nrows + 64 * R - 1) / (64 * R);
+  u64 zeros_all = 0;   // of every chunk of this wave: ONE atomic per wave (one per chunk put 10^5 atomics on the same address)
   for (int64_t chunk = (int64_t)blockIdx.x * NW + wv; chunk < nchunks; chunk += (int64_t)gridDim.x * NW) {
     const int64_t w0 = chunk * 64 * R;
     const u64 pos0 = p.grp_base[w0 >> 6];       // output bit position of the chunk's first selected row
@@ -1730,8 +1801,9 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactPara
       }
     }
     if (total > 0 && lo64 != 0) { if (lane == 0) atomicOr(&p.out_bits[wpos], (unsigned)lo64); }
-    if (p.zero_count && zeros && lane == 0) atomicAdd(p.zero_count, (u64)zeros);
+    zeros_all += zeros;
   }
+  if (p.zero_count && zeros_all && lane == 0) atomicAdd(p.zero_count, zeros_all);
 }
 
 // The same for a wave-packed batch group (FilterParams::group_bits_at): chunk c is wave slot c of the main launch -- 64 R
@@ -1744,6 +1816,7 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_group_kernel(const BitCompa
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int64_t nchunks = (int64_t)p.wpb * p.nb;
   const int R = p.rows_per_wave >> 6;
+  u64 zeros_all = 0;
   for (int64_t chunk = (int64_t)blockIdx.x * NW + wv; chunk < nchunks; chunk += (int64_t)gridDim.x * NW) {
     const int64_t b = chunk / p.wpb;
     const int64_t w0 = (chunk - b * p.wpb) * p.rows_per_wave;          // first row of the chunk inside its batch
@@ -1758,15 +1831,23 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_group_kernel(const BitCompa
     u64 lo64 = 0; u64 hi64 = 0; int total = shift0;
     bool head_shared = shift0 != 0;
     unsigned zeros = 0;
+    // lane j fetches slot j's selection word and 64 input bits up front (one coalesced load each for the whole chunk);
+    // the slot loop then reads them lane by lane -- fetched inside the loop they were R dependent round trips to memory per
+    // wave, and the kernel took longer than the main kernel it follows
+    u64 my_m = 0, my_in = 0;
+    if (lane < R) {
+      const u64 act = active_mask(w0 + 64 * lane, rows);
+      if (act) {
+        my_m = p.sel_mask[chunk * R + lane] & act;
+        my_in = bits ? load_bits64(bits, bitoff + w0 + 64 * lane, act) : act;
+      }
+    }
 #pragma unroll 1
     for (int j = 0; j < R; ++j) {
-      const int64_t r0 = w0 + 64 * j;
-      const u64 act = active_mask(r0, rows);
-      if (!act) break;
-      const u64 m = p.sel_mask[chunk * R + j] & act;
+      const u64 m = (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_m, j) | ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_m >> 32), j) << 32);
       const int cnt = __popcll(m);
-      if (cnt == 0) continue;
-      const u64 inb = bits ? load_bits64(bits, bitoff + r0, act) : act;
+      if (cnt == 0) continue;   // (nothing selected, or past the end of the batch)
+      const u64 inb = (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_in, j) | ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_in >> 32), j) << 32);
       const int mybit = (int)((inb >> lane) & 1);
       const bool sel = (m >> lane) & 1;
       const unsigned dst = sel ? lane_rank(m) : 63u - lane_rank(~m);
@@ -1786,8 +1867,9 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_group_kernel(const BitCompa
       }
     }
     if (total > 0 && lo64 != 0) { if (lane == 0) atomicOr(&p.out_bits[wpos], (unsigned)lo64); }
-    if (p.zero_count && zeros && lane == 0) atomicAdd(p.zero_count, (u64)zeros);
+    zeros_all += zeros;
   }
+  if (p.zero_count && zeros_all && lane == 0) atomicAdd(p.zero_count, zeros_all);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,9 +20,56 @@ static bool is_int(DType t) { return t >= T_I8 && t <= T_U64; }
 static bool is_signed(DType t) { return t >= T_I8 && t <= T_I64; }
 static bool is_float(DType t) { return t == T_F32 || t == T_F64; }
 static bool is_numeric(DType t) { return is_int(t) || is_float(t); }
-static bool is_wide(DType t) { return t == T_I64 || t == T_U64 || t == T_F64; }
+// (Float16 counts as wide: only the WIDE kernel instantiations carry its code, kernels.hip: f16_widen)
+static bool is_wide(DType t) { return t == T_I64 || t == T_U64 || t == T_F64 || t == T_F16; }
 
 [[noreturn]] static void fail(int code, const std::string& msg) { throw ChqError{code, msg}; }
+
+// ---- arrow-cast 53 cast_utf8_to_boolean (reached from RU/compute_value.rs:72-73, :95-96) -------------------------
+// value.to_ascii_lowercase().trim() against the accepted spellings; compute::cast runs with safe = true, so anything
+// else is NULL.  str::trim removes Unicode White_Space.  (unpinned-by-reference)
+static int ws_at(const uint8_t* p, int64_t n) {
+  if (n >= 1 && ((p[0] >= 0x09 && p[0] <= 0x0D) || p[0] == 0x20)) return 1;
+  if (n >= 2 && p[0] == 0xC2 && (p[1] == 0x85 || p[1] == 0xA0)) return 2;
+  if (n >= 3) {
+    if (p[0] == 0xE1 && p[1] == 0x9A && p[2] == 0x80) return 3;
+    if (p[0] == 0xE2 && p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) return 3;
+    if (p[0] == 0xE2 && p[1] == 0x81 && p[2] == 0x9F) return 3;
+    if (p[0] == 0xE3 && p[1] == 0x80 && p[2] == 0x80) return 3;
+  }
+  return 0;
+}
+int utf8_to_bool(const uint8_t* p, int64_t n) {
+  int w;
+  while (n > 0 && (w = ws_at(p, n)) > 0) { p += w; n -= w; }
+  for (bool again = true; again && n > 0;) {
+    again = false;
+    for (w = 1; w <= 3 && w <= n; ++w) if (ws_at(p + n - w, w) == w) { n -= w; again = true; break; }
+  }
+  if (n < 1 || n > 5) return -1;
+  char b[6];
+  for (int64_t i = 0; i < n; ++i) b[i] = (char)((p[i] >= 'A' && p[i] <= 'Z') ? p[i] + 32 : p[i]);
+  auto is = [&](const char* w) { return (int64_t)strlen(w) == n && !memcmp(b, w, (size_t)n); };
+  if (is("t") || is("tr") || is("tru") || is("true") || is("y") || is("ye") || is("yes") || is("on") || is("1")) return 1;
+  if (is("f") || is("fa") || is("fal") || is("fals") || is("false") || is("n") || is("no") || is("of") || is("off") || is("0")) return 0;
+  return -1;
+}
+
+// Temporal / decimal columns are compared with a column of the SAME DataType only (get_common_type's `left == right`
+// arm, RU/compute_value.rs:355); arrow-ord then compares the native values: i32 (Date32, Time32), i64 (Date64, Time64,
+// Timestamp, Duration), i128 (Decimal128).
+DType opaque_compare_class(const PlanColumn& c) {
+  const std::string& f = c.format;
+  if (f == "tdD" || f == "tts" || f == "ttm") return T_I32;
+  if (f == "tdm" || f == "ttu" || f == "ttn" || f.rfind("ts", 0) == 0 || f.rfind("tD", 0) == 0) return T_I64;
+  if (f.rfind("d:", 0) == 0 && c.width == 16) return T_FIXED_OPAQUE;
+  return T_NTYPES;
+}
+// "d:p,s" and "d:p,s,128" name the same DataType
+static std::string canonical_format(const std::string& f) {
+  if (f.rfind("d:", 0) == 0 && f.size() > 4 && f.compare(f.size() - 4, 4, ",128") == 0) return f.substr(0, f.size() - 4);
+  return f;
+}
 
 // ---- literal parsing: RU/compute_value.rs:219-265 -------------------------------------------------
 // Rust's <f32 as FromStr> grammar: [+-]? (inf|infinity|nan | digits [. digits*]? | . digits+) ([eE][+-]?digits)?
@@ -104,8 +151,15 @@ static void int_range_of(DType t, __int128* lo, __int128* hi) {
 }
 static __int128 as_i128(const Scalar& s) { return is_signed(s.type) ? (__int128)(int64_t)s.bits : (__int128)(uint64_t)s.bits; }
 
+static Scalar null_scalar(DType t) { Scalar s; s.type = t; s.null = true; return s; }
+
 static Scalar cast_scalar(const Scalar& s, DType to) {
   if (s.type == to) return s;
+  if (s.null) return null_scalar(to);
+  if (to == T_BOOL && s.type == T_UTF8) {
+    const int v = utf8_to_bool((const uint8_t*)s.str.data(), (int64_t)s.str.size());
+    return v < 0 ? null_scalar(T_BOOL) : scalar_bits(T_BOOL, (uint64_t)v);
+  }
   if (to == T_BOOL) {
     bool nz;
     if (s.type == T_F32) nz = bits_f32(s.bits) != 0.0f;
@@ -181,10 +235,12 @@ Scalar fold_constant(const TypedExpr& t, int ni) {
     case Node::CONST: return n.cval;
     case Node::CAST: return cast_scalar(fold_constant(t, n.l), n.type);
     case Node::TOBOOL: return cast_scalar(fold_constant(t, n.l), T_BOOL);
-    case Node::ARITH: return eval_arith(n.op, fold_constant(t, n.l), fold_constant(t, n.r));
-    case Node::CMP: return eval_cmp(n.op, fold_constant(t, n.l), fold_constant(t, n.r));
+    // (a NULL operand gives a NULL result; the operation -- and so its errors -- is evaluated on valid slots only)
+    case Node::ARITH: { Scalar a = fold_constant(t, n.l), b = fold_constant(t, n.r); return a.null || b.null ? null_scalar(n.type) : eval_arith(n.op, a, b); }
+    case Node::CMP: { Scalar a = fold_constant(t, n.l), b = fold_constant(t, n.r); return a.null || b.null ? null_scalar(T_BOOL) : eval_cmp(n.op, a, b); }
     case Node::ANDOR: {
       Scalar a = fold_constant(t, n.l), b = fold_constant(t, n.r);
+      if (a.null || b.null) return null_scalar(T_BOOL);   // non-Kleene: validity = union
       return scalar_bits(T_BOOL, n.op == OP_AND ? (a.bits & b.bits & 1) : ((a.bits | b.bits) & 1));
     }
     default: fail(CHQ_ERR_INVALID_HANDLE, "fold_constant on a column");
@@ -231,7 +287,6 @@ struct Typer {
   int cast_to(int ni, DType to) {
     if (t.nodes[ni].type == to) return ni;
     DType from = t.nodes[ni].type;
-    if (from == T_F16 || to == T_F16) fail(CHQ_ERR_NOT_SUPPORTED, "Float16 arithmetic is outside this build's scope");
     Node n{}; n.kind = Node::CAST; n.type = to; n.from = from; n.l = ni;
     n.is_scalar = t.nodes[ni].is_scalar; n.len1 = t.nodes[ni].len1;
     n.ref_order = t.nodes[ni].ref_order;
@@ -241,9 +296,7 @@ struct Typer {
   int to_bool(int ni) {   // compute::cast(x, &DataType::Boolean), RU/compute_value.rs:72-73,95-96
     DType from = t.nodes[ni].type;
     if (from == T_BOOL) return ni;
-    if (from == T_UTF8) fail(CHQ_ERR_NOT_SUPPORTED, "Utf8 -> Boolean cast is outside this build's scope");
-    if (from == T_F16) fail(CHQ_ERR_NOT_SUPPORTED, "Float16 is outside this build's scope");
-    if (!is_numeric(from)) fail(CHQ_ERR_ARROW_CAST, std::string("Casting from ") + dtype_name(from) + " to Boolean not supported");
+    if (!is_numeric(from) && from != T_F16 && from != T_UTF8) fail(CHQ_ERR_ARROW_CAST, std::string("Casting from ") + dtype_name(from) + " to Boolean not supported");
     Node n{}; n.kind = Node::TOBOOL; n.type = T_BOOL; n.from = from; n.l = ni;
     n.is_scalar = t.nodes[ni].is_scalar; n.len1 = t.nodes[ni].len1; n.ref_order = t.nodes[ni].ref_order;
     t.nodes.push_back(n);
@@ -334,7 +387,10 @@ struct Typer {
     }
     // cast_to_common_type, RU/compute_value.rs:433-461
     DType lt = t.nodes[l].type, rt = t.nodes[r].type, ct;
-    if (!common_type(lt, rt, &ct))
+    // (a temporal / decimal value is always a plain column: no literal and no operator produces one)
+    const bool both_opaque = lt == T_FIXED_OPAQUE && rt == T_FIXED_OPAQUE;
+    const bool same_opaque = both_opaque && canonical_format(cols[t.nodes[l].col].format) == canonical_format(cols[t.nodes[r].col].format);
+    if (!common_type(lt, rt, &ct) || (both_opaque && !same_opaque))
       fail(CHQ_ERR_UNSUPPORTED_TYPE_COERSION, std::string("unsupported type coersion for operation between types ") +
                                                   dtype_name(lt) + " and " + dtype_name(lt));
     l = cast_to(l, ct);
@@ -343,15 +399,31 @@ struct Typer {
     static const char* asym[] = {"+", "-", "*", "/", "%"};
     static const char* csym[] = {"==", "!=", "<", "<=", ">", ">="};
     if (aop >= 0) {
-      if (ct == T_F16) fail(CHQ_ERR_NOT_SUPPORTED, "Float16 arithmetic is outside this build's scope");
-      if (!is_numeric(ct))
+      if (ct == T_FIXED_OPAQUE) {
+        // arrow-arith 53 arithmetic_op: decimals and Duration +/- have arithmetic (not built here); dates and timestamps
+        // only subtract; everything else is "Invalid arithmetic operation" like any non-numeric type
+        const std::string& f = cols[ln.col].format;
+        const bool sub = aop == OP_SUB, addsub = aop == OP_ADD || sub;
+        if (f.rfind("d:", 0) == 0 || (f.rfind("tD", 0) == 0 && addsub) || ((f.rfind("td", 0) == 0 || f.rfind("ts", 0) == 0) && sub))
+          fail(CHQ_ERR_NOT_SUPPORTED, "arithmetic on '" + f + "' columns is outside this build's scope");
+      }
+      if (!is_numeric(ct) && ct != T_F16)
         fail(CHQ_ERR_ARROW_INVALID_ARGUMENT, std::string("Invalid arithmetic operation: ") + dtype_name(ct) + " " +
                                                  asym[aop - OP_ADD] + " " + dtype_name(ct));
       if (ln.is_scalar == rn.is_scalar && !same_len(ln, rn))
         fail(CHQ_ERR_ARROW_COMPUTE, "Cannot perform a binary operation on arrays of different length");
     } else {
-      if (ct == T_F16 || ct == T_FIXED_OPAQUE)
-        fail(CHQ_ERR_NOT_SUPPORTED, std::string("comparison of ") + dtype_name(ct) + " is outside this build's scope");
+      if (ct == T_FIXED_OPAQUE) {
+        const DType cls = opaque_compare_class(cols[ln.col]);
+        if (cls == T_NTYPES)
+          fail(CHQ_ERR_NOT_SUPPORTED, "comparison of '" + cols[ln.col].format + "' columns is outside this build's scope");
+        if (cls != T_FIXED_OPAQUE) {   // the raw values ARE Int32 / Int64: the same columns, read as integers
+          Node a = ln, b = rn; a.type = cls; b.type = cls;
+          t.nodes.push_back(a); l = (int)t.nodes.size() - 1;
+          t.nodes.push_back(b); r = (int)t.nodes.size() - 1;
+          ct = cls;
+        }
+      }
       if (ln.is_scalar == rn.is_scalar && !same_len(ln, rn))
         fail(CHQ_ERR_ARROW_INVALID_ARGUMENT, std::string("Cannot compare arrays of different lengths (") + csym[cop - OP_EQ] + ")");
     }
@@ -415,8 +487,9 @@ struct Gen {
   bool operandable(int ni) const {
     const Node& n = t.at(ni);
     if (n.type == T_UTF8) return false;
-    if (n.kind == Node::COL || n.kind == Node::CONST) return true;
-    if ((n.kind == Node::CAST || n.kind == Node::TOBOOL) && t.at(n.l).kind == Node::COL) return true;
+    if (n.kind == Node::CONST) return !n.cval.null;
+    if (n.kind == Node::COL) return true;
+    if ((n.kind == Node::CAST || n.kind == Node::TOBOOL) && n.from != T_UTF8 && t.at(n.l).kind == Node::COL) return true;
     return false;
   }
   void set_operand(Instr& in, int ni) {
@@ -443,16 +516,19 @@ struct Gen {
     in.ref_order = (uint8_t)n.ref_order;
     switch (n.kind) {
       case Node::COL:
-        if (n.type == T_UTF8 || n.type == T_FIXED_OPAQUE || n.type == T_F16)
+        if (n.type == T_UTF8 || n.type == T_FIXED_OPAQUE)
           fail(CHQ_ERR_NOT_SUPPORTED, std::string("computing on a ") + dtype_name(n.type) + " column is outside this build's scope");
         in.op = OP_LOAD; in.type = n.type; set_operand(in, ni); emit(in);
         return;
       case Node::CONST:
         if (n.type == T_UTF8) fail(CHQ_ERR_NOT_SUPPORTED, "Utf8 scalar in this position is outside this build's scope");
+        if (n.cval.null) fail(CHQ_ERR_NOT_SUPPORTED, "a NULL literal-built value in this position is outside this build's scope");
         in.op = OP_LOAD; in.type = n.type; set_operand(in, ni); emit(in);
         return;
       case Node::CAST:
       case Node::TOBOOL:
+        if (n.from == T_UTF8)   // not a device-program operation: the engine parses the column into a temporary first
+          fail(CHQ_INTERNAL_PROGRAM_LIMIT, "Utf8 -> Boolean cast runs as its own kernel");
         if (t.at(n.l).kind == Node::COL) { in.op = OP_LOAD; in.type = n.type; set_operand(in, ni); emit(in); return; }
         gen(n.l);
         in.op = n.kind == Node::CAST ? OP_CAST : OP_TOBOOL; in.type = n.type; in.src_type = n.from; in.src_kind = SRC_NONE;
@@ -460,6 +536,7 @@ struct Gen {
         return;
       case Node::CMP:
         if (n.from == T_UTF8) { gen_strcmp(n); return; }
+        if (n.from == T_FIXED_OPAQUE) fail(CHQ_INTERNAL_PROGRAM_LIMIT, "Decimal128 comparison runs as its own kernel");
         [[fallthrough]];
       case Node::ARITH:
       case Node::ANDOR: {

@@ -46,15 +46,26 @@ struct PlanColumn {
   bool has_nulls;
   std::vector<std::string> aliases;
   bool alias_entry_present;   // table_aliases vec has an entry for this column
+  std::string format;         // Arrow C format string: decides DataType equality of temporal / decimal columns
+  int width = 0;              // bytes per value of a fixed-width column
 };
 
 struct Scalar {
   DType type = T_BOOL;
   uint64_t bits = 0;          // value bits (sign-extended ints, IEEE bits for floats, 0/1 for bool)
   std::string str;            // utf8
+  bool null = false;          // only a Utf8 -> Boolean cast of a literal can make one (arrow-cast: bad spelling = NULL)
 };
 
+// arrow-cast 53 cast_utf8_to_boolean on one value: 1 / 0, or -1 when the spelling is not a boolean (= NULL, safe cast)
+int utf8_to_bool(const uint8_t* bytes, int64_t len);
+// how a temporal / decimal column compares with another of the SAME DataType: as I32 / I64 values, as 128-bit integers
+// (T_FIXED_OPAQUE returned, width 16), or not at all in this build (T_NTYPES)
+DType opaque_compare_class(const PlanColumn& c);
+
 struct Node {
+  // (a CMP whose `from` is T_FIXED_OPAQUE compares two Decimal128 columns, a TOBOOL whose `from` is T_UTF8 parses a Utf8
+  // column: neither runs inside a device program -- the engine evaluates them into temporary Boolean columns first)
   enum Kind { COL, CONST, ARITH, CMP, ANDOR, CAST, TOBOOL } kind;
   DType type;
   bool is_scalar;   // ArrayDatum.is_scalar

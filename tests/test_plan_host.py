@@ -18,7 +18,7 @@ from .helpers import load_golden
 
 TYPE_NAMES = {pa.bool_(): "Boolean", pa.int8(): "Int8", pa.int16(): "Int16", pa.int32(): "Int32", pa.int64(): "Int64",
               pa.uint8(): "UInt8", pa.uint16(): "UInt16", pa.uint32(): "UInt32", pa.uint64(): "UInt64",
-              pa.float32(): "Float32", pa.float64(): "Float64", pa.utf8(): "Utf8"}
+              pa.float16(): "Float16", pa.float32(): "Float32", pa.float64(): "Float64", pa.utf8(): "Utf8"}
 DATA_DEPENDENT = {20, 21}   # overflow / divide by zero: only the data can tell (unless the operands are literals)
 
 
