@@ -841,7 +841,8 @@ void materialize_node(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols,
 // kernels (typed_ops.hip) write a temporary Boolean column, which replaces the node like any other materialisation.
 bool is_typed_op(const TypedExpr& te, int node) {
   const Node& n = te.nodes[node];
-  return (n.kind == Node::CMP && n.from == T_FIXED_OPAQUE) || (n.kind == Node::TOBOOL && n.from == T_UTF8);
+  return (n.kind == Node::CMP && n.from == T_FIXED_OPAQUE) || (n.kind == Node::TOBOOL && n.from == T_UTF8) ||
+         (n.kind == Node::CONST && n.cval.null);   // `'maybe' AND ..` folded to NULL, next to a column of a one-row batch
 }
 void materialize_typed_op(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te, int node) {
   const Node n = te.nodes[node];
@@ -850,7 +851,12 @@ void materialize_typed_op(Context& ctx, Batch& work, std::vector<PlanColumn>& wc
   auto bits = make_device_buffer(words * 8, ctx.device), valid = make_device_buffer(words * 8, ctx.device);
   auto count = make_device_buffer(16, ctx.device);
   check_hip(hipMemsetAsync(count->ptr, 0, 16, ctx.stream), "memset");
-  if (n.kind == Node::CMP) {
+  if (n.kind == Node::CONST) {
+    check_hip(hipMemsetAsync(bits->ptr, 0, words * 8, ctx.stream), "memset");
+    check_hip(hipMemsetAsync(valid->ptr, 0, words * 8, ctx.stream), "memset");
+    const u64 all = (u64)nrows;
+    check_hip(hipMemcpyAsync(count->ptr, &all, 8, hipMemcpyHostToDevice, ctx.stream), "null count");
+  } else if (n.kind == Node::CMP) {
     const Column& a = work.cols[(size_t)te.nodes[n.l].col];
     const Column& b = work.cols[(size_t)te.nodes[n.r].col];
     Cmp128Params p{};
@@ -888,8 +894,8 @@ void materialize_typed_op(Context& ctx, Batch& work, std::vector<PlanColumn>& wc
 }
 
 void fit_subtree(Context& ctx, Batch& work, std::vector<PlanColumn>& wcols, TypedExpr& te, int node, bool strict, bool is_root) {
-  if (is_leaf_node(te.nodes[node])) return;
   if (is_typed_op(te, node)) { materialize_typed_op(ctx, work, wcols, te, node); return; }
+  if (is_leaf_node(te.nodes[node])) return;
   const int l = te.nodes[node].l, r = te.nodes[node].r;
   if (l >= 0) fit_subtree(ctx, work, wcols, te, l, strict, false);
   if (r >= 0) fit_subtree(ctx, work, wcols, te, r, strict, false);

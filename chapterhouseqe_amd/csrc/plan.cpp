@@ -522,7 +522,8 @@ struct Gen {
         return;
       case Node::CONST:
         if (n.type == T_UTF8) fail(CHQ_ERR_NOT_SUPPORTED, "Utf8 scalar in this position is outside this build's scope");
-        if (n.cval.null) fail(CHQ_ERR_NOT_SUPPORTED, "a NULL literal-built value in this position is outside this build's scope");
+        if (n.cval.null)   // (only met next to a column of a ONE-row batch: the engine makes it a one-row all-null temporary column)
+          fail(CHQ_INTERNAL_PROGRAM_LIMIT, "a NULL literal-built value is not a program constant");
         in.op = OP_LOAD; in.type = n.type; set_operand(in, ni); emit(in);
         return;
       case Node::CAST:

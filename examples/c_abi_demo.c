@@ -86,6 +86,22 @@ static void release_out(struct ArrowDeviceArray* a, struct ArrowSchema* s) {
     }                                                                                   \
   } while (0)
 
+/* Position-weighted digest of an output batch (arithmetic modulo 2^64): sum over columns c of W[c] * sum over rows k of
+ * bits32(col_c[k]) * (k + 1).  The tests compare the digests this program prints with tests/golden/c_abi_demo_expected.json,
+ * which scripts/make_c_abi_demo_fixture.py produced by running the ORACLE on the same generated data in the build container
+ * (the scalar loop below stays as the in-program check). */
+static uint64_t digest_columns(const struct ArrowArray* out, int ncols) {
+  static const uint64_t W[3] = {1, 3, 7};
+  uint64_t d = 0;
+  for (int c = 0; c < ncols; ++c) {
+    const uint32_t* v = (const uint32_t*)out->children[c]->buffers[1] + out->children[c]->offset;
+    uint64_t s = 0;
+    for (int64_t k = 0; k < out->length; ++k) s += (uint64_t)v[k] * (uint64_t)(k + 1);
+    d += W[c] * s;
+  }
+  return d;
+}
+
 /* expected survivors of `value2 > 10.0` in rows [r0, r0 + n) */
 static int64_t expect_rows(const float* v2, int64_t r0, int64_t n) {
   int64_t k = 0;
@@ -130,6 +146,8 @@ int main(int argc, char** argv) {
   /* value2 > 10.0  as  BinaryOp { Identifier("value2"), Gt, Value(Number("10.0", false)) } */
   chq_expr* pred = chq_expr_binary_op(chq_expr_identifier("value2"), CHQ_BINOP_GT, ">", chq_expr_number("10.0", 0));
   int failures = 0;
+  uint64_t d_loop = 0, d_group = 0, d_join = 0, d_counts = 0, d_project = 0;
+  int64_t n_loop = 0, n_group = 0, n_join = 0, n_project = 0;
 
   /* 1. one batch at a time: the reference's loop */
   double t0 = now_ms();
@@ -139,6 +157,7 @@ int main(int argc, char** argv) {
       struct ArrowDeviceArray out; struct ArrowSchema out_schema;
       CHECK(chq_filter_record(ctx, ptrs[b], &g_schema, NULL, pred, ARROW_DEVICE_CPU, &out, &out_schema));
       if (rep == 1 && !check_filtered(&out.array, id, v1, v2, b * rows, rows)) ++failures;
+      if (rep == 1) { d_loop += (uint64_t)(b + 1) * digest_columns(&out.array, 3); n_loop += out.array.length; }
       release_out(&out, &out_schema);
     }
   }
@@ -154,6 +173,7 @@ int main(int argc, char** argv) {
     t_group = now_ms() - t0;
     for (int b = 0; b < nb; ++b) {
       if (rep == 1 && !check_filtered(&outs[b].array, id, v1, v2, b * rows, rows)) ++failures;
+      if (rep == 1) { d_group += (uint64_t)(b + 1) * digest_columns(&outs[b].array, 3); n_group += outs[b].array.length; }
       release_out(&outs[b], &out_schemas[b]);
     }
   }
@@ -171,6 +191,8 @@ int main(int argc, char** argv) {
     if (rep == 1) {
       if (!check_filtered(&out.array, id, v1, v2, 0, total)) ++failures;
       for (int b = 0; b < nb; ++b) if (per_record[b] != expect_rows(v2, b * rows, rows)) ++failures;
+      d_join = digest_columns(&out.array, 3); n_join = out.array.length;
+      for (int b = 0; b < nb; ++b) d_counts += (uint64_t)(b + 1) * (uint64_t)per_record[b];
     }
     release_out(&out, &out_schema);
   }
@@ -192,6 +214,7 @@ int main(int argc, char** argv) {
       ++k;
     }
     if (k != out.array.length || strcmp(out_schema.children[1]->name, "twice") != 0) ++failures;
+    d_project = digest_columns(&out.array, 2); n_project = out.array.length;
     release_out(&out, &out_schema);
   }
 
@@ -200,6 +223,10 @@ int main(int argc, char** argv) {
   printf("  chq_filter_records (one call)     : %8.3f ms  (%lld kernel launch%s)\n", t_group, (long long)stats.launches, stats.launches == 1 ? "" : "es");
   printf("  chq_filter_records_coalesced      : %8.3f ms\n", t_join);
   printf("  mismatches against the scalar loop: %d\n", failures);
+  printf("digest filter_record rows=%lld sum=%016llx\n", (long long)n_loop, (unsigned long long)d_loop);
+  printf("digest filter_records rows=%lld sum=%016llx\n", (long long)n_group, (unsigned long long)d_group);
+  printf("digest filter_records_coalesced rows=%lld sum=%016llx counts=%016llx\n", (long long)n_join, (unsigned long long)d_join, (unsigned long long)d_counts);
+  printf("digest filter_project_record rows=%lld sum=%016llx\n", (long long)n_project, (unsigned long long)d_project);
 
   chq_expr_free(pred); chq_expr_free(twice); chq_expr_free(id_expr);
   chq_ctx_destroy(ctx);

@@ -89,7 +89,17 @@ void* chq_ctx_stream(const chq_ctx* ctx);
  * "time_kernels", "trim_pool" (return every cached HBM / host block to the system), "host_pool_bytes" (cap of the
  * process-wide cache of host result buffers, default 8 GiB, 0 disables it), "fuse" (chq_filter_project_record's
  * single-pass kernel: 0 never, 1 = default: when it moves clearly fewer bytes than the two steps, 2 whenever the
- * inputs allow), "group_mode" (chq_filter_records layout: 0 auto, 1 per-tile table, 2 wave-packed). Unknown keys fail. */
+ * inputs allow), "group_mode" (chq_filter_records layout: 0 auto, 1 per-tile table, 2 wave-packed).  Switches that exist for A/B
+ * measurements and tests (all default 1): "fold_utf8" (short-string Utf8 columns inside the main kernel), "group_fold"
+ * (the same for batch groups), "group_bits" (validity bitmaps / Boolean columns of a wave-packed device group in the
+ * one-launch path), "stash" (-1 auto .. 2 predicate columns kept in LDS between the two phases), "split_rows" (rows from
+ * which a batch is launched as complete tiles + tail).  Unknown keys fail.
+ *
+ * Type coverage of expressions = the reference's (RU/compute_value.rs:350-431): the integer / float coercion table,
+ * Utf8 and Boolean comparisons, Float16 (widening, f16 arithmetic and comparisons), same-type comparisons of Date32 /
+ * Date64 / Time32 / Time64 / Timestamp / Duration / Decimal128 columns, and casts to Boolean under AND / OR from numeric
+ * and Utf8 operands (a spelling arrow-cast does not know is NULL).  CHQ_ERR_NOT_SUPPORTED remains for ARITHMETIC on
+ * decimals, durations and date / timestamp differences, and for comparisons of FixedSizeBinary / interval columns. */
 chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value);
 /* Counters of the last filter call: rows in, rows out, tiles, kernel launches. */
 typedef struct chq_call_stats {

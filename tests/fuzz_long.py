@@ -15,7 +15,8 @@ from oracle import oracle as O
 
 from .cases import empty_aliases
 from .helpers import arrays_identical, batches_identical, explain_diff
-from .test_gpu_parity import FAMILIES, FAMILY_WEIGHTS, make_batch, random_numeric, random_predicate
+from .test_gpu_parity import (FAMILIES, FAMILY_WEIGHTS, make_batch, make_typed_batch, random_numeric, random_predicate,
+                              random_typed_predicate, random_typed_value)
 
 SIZES = [1, 2, 63, 64, 65, 511, 2047, 2048, 2049, 4100, 16383, 16384, 16385, 33000, 70001]
 
@@ -139,9 +140,18 @@ def main():
         if rng.random() < 0.3 and n > 10:
             start = int(rng.integers(0, min(9, n - 1)))
             rec = rec.slice(start, n - start - int(rng.integers(0, 3)))
+        # one case in seven runs on the temporal / decimal / Float16 / boolean-word columns (same-type comparisons, f16
+        # arithmetic, Utf8 under AND / OR) through the same entry points
+        typed_cols = rng.random() < 1.0 / 7.0
+        if typed_cols:
+            rec = make_typed_batch(n, int(rng.integers(0, 2**31)), nulls=bool(rng.random() < 0.7))
+        gen_pred = (lambda d: random_typed_predicate(rng, min(d, 3))) if typed_cols else (lambda d: random_predicate(rng, d))
+        gen_num = (lambda d: random_typed_value(rng)) if typed_cols else (lambda d: random_numeric(rng, d))
         al = empty_aliases(rec)
         ctx = ctxs[int(rng.integers(0, len(ctxs)))]
         mode = rng.random()
+        if typed_cols and 0.9 <= mode < 0.95:
+            mode = 0.97   # (the numeric-only group mode picks its columns by name)
         if rng.random() < 0.35:
             # random schemas (types, order, duplicate names, nulls, NaN / inf / signed zeros) and table aliases
             rec, al = random_schema_batch(rng, int(rng.choice([0, 1, 2, 5, 64, 65, 700, 2049, 20000])))
@@ -197,7 +207,7 @@ def main():
                 return 1
             continue
         if mode < 0.45:
-            sql = random_predicate(rng, int(rng.integers(1, 4)))
+            sql = gen_pred(int(rng.integers(1, 4)))
             e = parse_expr(sql)
             ec, exp = outcome(lambda: O.filter_record(rec, al, e))
             src = chq.DeviceRecordBatch.from_host(rec, ctx) if rng.random() < 0.5 else rec
@@ -207,15 +217,15 @@ def main():
             kind = "filter"
             same = got is None or batches_identical(got, exp)
         elif mode < 0.7:
-            sql = random_numeric(rng, 3) if rng.random() < 0.6 else random_predicate(rng, 2)
+            sql = gen_num(3) if rng.random() < 0.6 else gen_pred(2)
             e = parse_expr(sql)
             ec, exp = outcome(lambda: O.compute_value(rec, al, e)[0])
             gc, got = outcome(lambda: chq.compute_value(rec, al, e, ctx=ctx)[0])
             kind = "value"
             same = got is None or arrays_identical(got, exp, nan_payload=True)
         elif mode < 0.85:
-            items = ", ".join([random_numeric(rng, 2) + f" as c{k}" for k in range(int(rng.integers(1, 4)))] + (["*"] if rng.random() < 0.3 else []))
-            sql = f"select {items} from t where {random_predicate(rng, 2)}"
+            items = ", ".join([gen_num(2) + f" as c{k}" for k in range(int(rng.integers(1, 4)))] + (["*"] if rng.random() < 0.3 else []))
+            sql = f"select {items} from t where {gen_pred(2)}"
             sel = parse_select(sql)
             ec, exp = outcome(lambda: O.project_record(sel.projection, O.filter_record(rec, al, sel.selection), al))
             if rng.random() < 0.5:
@@ -226,7 +236,7 @@ def main():
             same = got is None or batches_identical(got, exp, nan_payload=True)
         elif mode < 0.9:
             # deep expressions: beyond one device program -> sub-trees become temporary columns (fit_to_device)
-            sql = random_numeric(rng, int(rng.integers(4, 7))) if rng.random() < 0.5 else random_predicate(rng, int(rng.integers(3, 5)))
+            sql = gen_num(int(rng.integers(4, 7))) if rng.random() < 0.5 else gen_pred(int(rng.integers(3, 5)))
             e = parse_expr(sql)
             ec, exp = outcome(lambda: O.compute_value(rec, al, e)[0])
             src = chq.DeviceRecordBatch.from_host(rec, ctx) if rng.random() < 0.5 else rec
@@ -285,7 +295,7 @@ def main():
             ctx.set_option("group_mode", 0)
             kind = "group1"
         else:
-            sql = random_predicate(rng, 2)
+            sql = gen_pred(2)
             e = parse_expr(sql)
             k = int(rng.integers(2, 6))
             cut = sorted(set(int(x) for x in rng.integers(0, max(1, rec.num_rows), k)))

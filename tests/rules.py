@@ -117,6 +117,10 @@ def batch_bool_words():
     ], names=["s", "b", "id"])
 
 
+def batch_one_row():
+    return pa.RecordBatch.from_arrays([pa.array([7], pa.uint64()), pa.array(["yes"], pa.utf8())], names=["b", "w"])
+
+
 # (name, batch factory, kind, sql / select, expectation)
 # kind "value": expectation = (arrow type, python list)   [compute_value]
 # kind "filter": expectation = list of surviving row indices of the input batch
@@ -249,6 +253,10 @@ RULES = [
     ("utf8_literals_under_and", batch_bool_words, "value", "'yes' and 'off'", (pa.bool_(), [False])),
     ("utf8_bad_literal_is_null", batch_bool_words, "value", "'maybe' or 'true'", (pa.bool_(), [None])),
     ("utf8_literal_vs_column_length_mismatch", batch_bool_words, "error", "'true' and id > 0", 23),
+    # a one-row batch is the only place where a literal-built array meets a column without a length error
+    ("utf8_null_literal_next_to_a_one_row_column", batch_one_row, "value", "b and ('b' and 2.5)", (pa.bool_(), [None])),
+    ("utf8_literal_next_to_a_one_row_column", batch_one_row, "value", "w and ('on' or false)", (pa.bool_(), [True])),
+    ("utf8_null_literal_filters_nothing", batch_one_row, "filter", "b and ('b' and 2.5)", []),
     # ---- and / or take plain BooleanArrays: no scalar broadcast, result is never a scalar ---------------------
     ("and_with_literal_length_mismatch", batch_ints, "error", "i > 0 and true", 23),
     ("or_with_literal_length_mismatch", batch_ints, "error", "false or i > 0", 23),

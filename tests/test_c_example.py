@@ -1,8 +1,11 @@
 """The C ABI from plain C (examples/c_abi_demo.c, gcc, no Python / torch / C++ on the caller's side): every entry point
 of the path -- chq_filter_record, chq_filter_records, chq_filter_records_coalesced, chq_filter_project_record -- over
-hand-built Arrow C Data structs, checked inside the program against a scalar loop."""
+hand-built Arrow C Data structs, checked inside the program against a scalar loop AND, by the digests it prints, against
+tests/golden/c_abi_demo_expected.json: the oracle's results on the same generated data (scripts/make_c_abi_demo_fixture.py)."""
+import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -35,3 +38,13 @@ def test_demo_matches_its_scalar_loop(rows, batches):
     r = subprocess.run([EXE, str(rows), str(batches)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches against the scalar loop: 0" in r.stdout
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "c_abi_demo_expected.json")))["cases"][f"{rows}x{batches}"]
+    got = [line for line in r.stdout.splitlines() if line.startswith("digest ")]
+    assert got == want, "\n".join(["demo:"] + got + ["oracle fixture:"] + want)
+
+
+def test_the_committed_fixture_is_what_the_oracle_produces():
+    """regenerate the fixture (oracle on the demo's LCG data, CPU only) and compare with the committed file"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "make_c_abi_demo_fixture.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == json.load(open(os.path.join(ROOT, "tests", "golden", "c_abi_demo_expected.json")))

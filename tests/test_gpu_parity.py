@@ -304,6 +304,107 @@ def test_fuzz_compute_value_vs_oracle(ctx, n):
     assert outcomes["ok"] >= 20 and outcomes["unsupported"] <= 3, outcomes
 
 
+# ---- the reference's remaining type coverage: temporal / decimal same-type comparisons, Float16, Utf8 under AND / OR -------
+def make_typed_batch(n, seed, nulls=True):
+    import decimal
+    rng = np.random.default_rng(seed)
+
+    def m(p):
+        return (rng.random(n) < p) if nulls and n else None
+
+    def raw(typ, lo, hi, p=0.0):
+        a = pa.array(rng.integers(lo, hi, n).astype(np.int32 if typ.bit_width == 32 else np.int64), mask=m(p))
+        return a.view(typ)
+
+    def dec(p=0.0):
+        vals = [decimal.Decimal(int(x) * 2**40 + int(y)) / 100 for x, y in zip(rng.integers(-2**30, 2**30, n), rng.integers(0, 4, n))]
+        return pa.array(vals, pa.decimal128(30, 2), mask=m(p)) if n else pa.array([], pa.decimal128(30, 2))
+
+    halves = np.concatenate([np.array([0.0, -0.0, 1.0, 0.5, 65504.0, 6e-8, np.inf, -np.inf], dtype=np.float16),
+                             (rng.standard_normal(64) * 8).astype(np.float16)])
+    words = np.array(["true", "false", " yes", "NO ", "t", "0", "1", "off", "maybe", "", "on", "\u2003Y\u00a0", "fals", "truee"])
+    cols = {
+        "h": pa.array(halves[rng.integers(0, len(halves), n)], pa.float16(), mask=m(0.1)),
+        "k": pa.array(halves[rng.integers(0, len(halves), n)], pa.float16()),
+        "f32": pa.array((rng.random(n) * 20 - 10).astype(np.float32)),
+        "f64": pa.array(rng.random(n) * 200 - 100, mask=m(0.05)),
+        "i32": pa.array(rng.integers(-1000, 1001, n).astype(np.int32)),
+        "d1": raw(pa.date32(), -5, 6, 0.1), "d2": raw(pa.date32(), -5, 6),
+        "t1": raw(pa.timestamp("us"), -2**40, 2**40), "t2": raw(pa.timestamp("us"), -2**40, 2**40, 0.1),
+        "u1": raw(pa.time32("s"), 0, 10), "u2": raw(pa.time32("s"), 0, 10),
+        "x1": dec(0.1), "x2": dec(),
+        "w": pa.array(words[rng.integers(0, len(words), n)] if n else np.array([], dtype=object), type=pa.utf8(), mask=m(0.1)),
+        "flag": pa.array(rng.integers(0, 2, n).astype(bool), mask=m(0.2)),
+    }
+    return pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols.keys()))
+
+
+def random_typed_value(rng):
+    ops = ["+", "*", "/", "%", "+"]
+    r = rng.random()
+    if r < 0.4:
+        return f"h {rng.choice(ops)} k"
+    if r < 0.6:
+        return f"(h {rng.choice(ops)} k) {rng.choice(ops)} h"
+    if r < 0.8:
+        return f"h {rng.choice(ops)} {rng.choice(['f32', 'f64', '1.5', '(k + f32)'])}"
+    return f"k {rng.choice(ops)} (f64 {rng.choice(ops)} h)"
+
+
+def random_typed_predicate(rng, depth):
+    cmp = lambda: str(rng.choice(["<", "<=", ">", ">=", "=", "<>"]))
+    if depth == 0 or rng.random() < 0.4:
+        r = rng.random()
+        if r < 0.3:
+            a, b = [("d1", "d2"), ("t1", "t2"), ("u1", "u2"), ("x1", "x2"), ("x2", "x1"), ("d2", "d2")][int(rng.integers(0, 6))]
+            return f"{a} {cmp()} {b}"
+        if r < 0.5:
+            return f"h {cmp()} k"
+        if r < 0.7:
+            return f"{random_typed_value(rng)} {cmp()} {rng.choice(['h', 'f32', 'f64', '0.5'])}"
+        if r < 0.85:
+            return str(rng.choice(["w", "h", "flag", "k"]))
+        return f"i32 {cmp()} {int(rng.integers(0, 500))}"
+    return f"({random_typed_predicate(rng, depth - 1)} {rng.choice(['and', 'or'])} {random_typed_predicate(rng, depth - 1)})"
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000, 16385, 70_000])
+def test_fuzz_typed_columns_vs_oracle(ctx, n):
+    rng = np.random.default_rng(4000 + n)
+    rec = make_typed_batch(n, n)
+    al = empty_aliases(rec)
+    outcomes = {"ok": 0, "error": 0, "unsupported": 0}
+    for _ in range(14):
+        outcomes[check_same(ctx, rec, al, random_typed_predicate(rng, 2), "filter")] += 1
+    for _ in range(10):
+        sql = random_typed_value(rng) if rng.random() < 0.5 else random_typed_predicate(rng, 1)
+        outcomes[check_same(ctx, rec, al, sql, "value")] += 1
+    # a top-level Float16 / Utf8 column is not a Boolean mask (CastToBooleanArrayFailed on both sides): a few errors are expected
+    assert outcomes["ok"] >= 16 and outcomes["unsupported"] == 0, outcomes
+
+
+def test_typed_columns_through_projection_and_groups(ctx):
+    """the same operations behind the other entry points: projection outputs of type Float16, the fused filter + projection,
+    and a device-resident batch group (per-batch fallback: typed operations materialise temporaries per batch)"""
+    rec = make_typed_batch(30_000, 3)
+    al = empty_aliases(rec)
+    sel = parse_select("select h + k as s, h * f32 as p, x1 < x2 as lt, d1, w from t where (t1 <= t2 or w) and h >= k")
+    exp = O.project_record(sel.projection, O.filter_record(rec, al, sel.selection), al)
+    dev = chq.DeviceRecordBatch.from_host(rec, ctx)
+    two = chq.project_record(sel.projection, chq.filter_record(dev, al, sel.selection, ctx=ctx), al, ctx=ctx).to_host()
+    assert batches_identical(two, exp, nan_payload=True), explain_diff(two, exp)
+    one = chq.filter_project_record(sel.selection, sel.projection, dev, al, ctx=ctx).to_host()
+    assert batches_identical(one, exp, nan_payload=True), explain_diff(one, exp)
+    parts = [make_typed_batch(5000, 10 + i) for i in range(6)]
+    devs = [chq.DeviceRecordBatch.from_host(p, ctx) for p in parts]
+    for sql in ["d1 < d2", "x1 >= x2 and i32 > 0", "h < k or w", "h + k > f32"]:
+        e = parse_expr(sql)
+        outs = chq.filter_records(devs, al, e, ctx=ctx)
+        for p, o in zip(parts, outs):
+            want = O.filter_record(p, al, e)
+            assert batches_identical(o.to_host(), want), f"{sql}:\n{explain_diff(o.to_host(), want)}"
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("tile_kind", [0, 1, 2])
 @pytest.mark.parametrize("n", [1, 2048, 16384, 16385, 40_000])
