@@ -127,6 +127,7 @@ struct Context {
   int64_t opt_large_host_rows = 8 << 20;
   int64_t opt_large_host_chunk = 0;  // rows per chunk (0: about 64 MB of input)
   int64_t opt_group_bits = 1;       // wave-packed device groups with validity bitmaps / Boolean columns take the one-launch path (0: joined first)
+  int64_t opt_parquet_page_rows = 65536;   // chq_record_to_parquet: rows per data page (multiples of 4096; at most 64 pages per chunk)
   int64_t opt_group_fold = 1;       // device-resident groups with short-string Utf8 columns: filtered straight out of the batches (0: joined first)
   int64_t opt_fold_utf8 = 1;        // short-string Utf8 columns are filtered inside filter_fused_kernel (0: always the separate Utf8 pass)
   int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots

@@ -113,6 +113,21 @@ struct PwParams {
   int64_t n_blocks;                 // ceil(n_rows / PW_BLOCK_ROWS_HOST)
   unsigned long long* total_bytes;
 };
+// pw_stats_kernel: min / max of the non-null (and, for floats, non-NaN) values of a column, for the chunk's Statistics.
+// Numbers travel as order-preserving int64 keys (floats: the IEEE totalOrder key); Utf8 as the ROW of the smallest /
+// largest value in unsigned byte order.
+enum PwStatsKind { PW_STATS_I32 = 0, PW_STATS_I64, PW_STATS_F32, PW_STATS_F64, PW_STATS_U8, PW_STATS_UTF8 };
+struct PwStatsParams {
+  int64_t n_rows;
+  const uint8_t* validity; int64_t bit_offset;
+  const uint8_t* values;        // fixed-width values at row 0 (PW_STATS_U8: one byte per row)
+  const int32_t* offsets; const uint8_t* data;   // Utf8
+  int32_t kind; int32_t pad;
+  long long* out;               // [3]: min key / row, max key / row, number of values that took part; host-initialised
+  long long* cand;              // Utf8: [2 * grid] per-block candidates
+  int32_t n_cand; int32_t pad2; // Utf8, second launch: number of blocks of the first
+};
+hipError_t pw_launch_stats(const PwStatsParams& p, int grid, hipStream_t s);
 constexpr int PW_BLOCK_ROWS_HOST = 4096;   // = PW_BLOCK_ROWS of parquet_write.hip
 hipError_t pw_launch_scan(const PwParams& p, hipStream_t s);
 hipError_t pw_launch_encode(const PwParams& p, hipStream_t s);

@@ -5,9 +5,11 @@
 // row group per record).  The value streams of the data pages are produced in HBM (parquet_write.hip; a non-null
 // fixed-width column needs no kernel, its Arrow buffer IS the PLAIN stream), copied once into their place in the file
 // image; page headers and the footer (FileMetaData) are written here with a small Thrift compact-protocol writer.
-// Output format: PLAIN encoding, UNCOMPRESSED, data pages V1, one page per column chunk, definition levels = the Arrow
-// validity bitmap behind a one-run header.  Any Parquet reader decodes it (tests: pyarrow, and this library's own scan);
-// it is NOT byte-identical to what the parquet crate writes (that one dictionary-encodes and adds statistics).
+// Output format: PLAIN encoding, UNCOMPRESSED, data pages V1 of `parquet_page_rows` rows (default 65 536, at most 64 pages
+// per chunk), definition levels = the Arrow validity bitmap behind a one-run header per page, chunk statistics (null_count,
+// min_value / max_value, TypeDefinedOrder) like the parquet crate's writer records them.  Any Parquet reader decodes it
+// (tests: pyarrow, and this library's own scan); it is NOT byte-identical to what the parquet crate writes (that one
+// dictionary-encodes first and adds page indexes).
 // Types: Int32, Int64, Float32, Float64, Boolean, Utf8; anything else CHQ_ERR_NOT_SUPPORTED.
 #include <cstring>
 
@@ -49,15 +51,27 @@ struct Piece { int64_t at; const void* src; int64_t bytes; };   // device bytes 
 struct ColumnPlan {
   int physical = 0;
   bool optional = false, string = false;
-  std::vector<uint8_t> levels;      // host part of the level section: [u32 length][run header ...]; the bitmap bytes follow from the device
-  const uint8_t* levels_dev = nullptr; int64_t levels_dev_bytes = 0;
+  const uint8_t* levels_dev = nullptr;   // optional column with nulls: the validity bits from bit 0 (definition levels, bit width 1)
   const void* stream = nullptr; int64_t stream_bytes = 0;
   std::vector<BufferPtr> keep;
   int64_t null_count = -1;
+  bool has_minmax = false;
+  std::string min_value, max_value;   // Statistics.min_value / max_value: PLAIN encoding of the value (Utf8: the bytes)
   BufferPtr block_sums;
   PwParams enc{};
   bool needs_scan = false, boolean = false;
   BufferPtr bool_bytes;
+  bool has_validity = false;
+  std::vector<unsigned long long> prefix;   // several pages: bytes of the value stream in front of every 4096-row block
+};
+
+// one data page of a column chunk
+struct PagePlan {
+  int64_t rows = 0;
+  std::vector<uint8_t> head;                // Thrift page header + the host part of the level section
+  const uint8_t* levels_dev = nullptr; int64_t levels_dev_bytes = 0;
+  const uint8_t* stream = nullptr; int64_t stream_bytes = 0;
+  int64_t total() const { return (int64_t)head.size() + levels_dev_bytes + stream_bytes; }
 };
 
 }  // namespace
@@ -70,8 +84,24 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   std::vector<ColumnPlan> plan(nc);
   const int grid = ctx.num_cus * 8;
   const int64_t n_blocks = std::max<int64_t>(1, (rows + PW_BLOCK_ROWS_HOST - 1) / PW_BLOCK_ROWS_HOST);
+  // Several pages per chunk (round 3): pages are what a reader decodes in parallel (this library's scan: one workgroup per
+  // page), the parquet crate cuts them at ~1 MiB.  Page boundaries sit on multiples of 4096 rows (the block size of the
+  // stream scan, and a whole number of level bytes); at most 64 pages per chunk, so that a file image needs a bounded
+  // number of device-to-host copies.
+  int64_t page_rows = std::max<int64_t>(PW_BLOCK_ROWS_HOST, ctx.opt_parquet_page_rows / PW_BLOCK_ROWS_HOST * PW_BLOCK_ROWS_HOST);
+  if (rows > 64 * page_rows) page_rows = ((rows + 63) / 64 + PW_BLOCK_ROWS_HOST - 1) / PW_BLOCK_ROWS_HOST * PW_BLOCK_ROWS_HOST;
+  const int64_t n_pages = std::max<int64_t>(1, (rows + page_rows - 1) / page_rows);
   auto totals = make_device_buffer(8 * (nc + 1), ctx.device);
   check_hip(hipMemsetAsync(totals->ptr, 0, 8 * (nc + 1), ctx.stream), "memset");
+  // chunk statistics (round 3): min / max per column, like the parquet crate's writer (EnabledStatistics default)
+  std::vector<long long> h_stats(3 * nc);
+  for (size_t ci = 0; ci < nc; ++ci) {
+    const bool str = rec.cols[ci].type == T_UTF8;
+    h_stats[3 * ci] = str ? -1 : INT64_MAX; h_stats[3 * ci + 1] = str ? -1 : INT64_MIN; h_stats[3 * ci + 2] = 0;
+  }
+  auto d_stats = make_device_buffer(24 * nc + 16, ctx.device);
+  if (nc) check_hip(hipMemcpyAsync(d_stats->ptr, h_stats.data(), 24 * nc, hipMemcpyHostToDevice, ctx.stream), "init statistics");
+  std::vector<BufferPtr> stats_keep;
 
   // ---- phase 1: sizes (scan of the bytes every row contributes) ------------------------------------------------------
   for (size_t ci = 0; ci < nc; ++ci) {
@@ -90,6 +120,7 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
     const bool has_validity = c.validity && c.null_count != 0;
     if (has_validity && !c.nullable) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: column '" + c.name + "' is declared non-nullable but carries a validity bitmap"};
     pl.null_count = has_validity ? c.null_count : 0;
+    pl.has_validity = has_validity;
     PwParams& e = pl.enc;
     e.n_rows = rows; e.validity = has_validity ? c.validity : nullptr; e.bit_offset = c.offset;
     e.n_blocks = n_blocks; e.total_bytes = (unsigned long long*)totals->ptr + ci;
@@ -103,16 +134,76 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
         e.values = (const uint8_t*)pl.bool_bytes->ptr;
       }
     } else { e.width = c.width; e.values = (const uint8_t*)c.values0(); }
+    if (rows > 0) {
+      PwStatsParams sp{};
+      sp.n_rows = rows; sp.validity = e.validity; sp.bit_offset = c.offset; sp.values = e.values;
+      sp.offsets = e.offsets; sp.data = e.data; sp.out = (long long*)d_stats->ptr + 3 * ci;
+      sp.kind = pl.string ? PW_STATS_UTF8 : pl.boolean ? PW_STATS_U8 : c.type == T_I32 ? PW_STATS_I32 : c.type == T_I64 ? PW_STATS_I64 :
+                c.type == T_F32 ? PW_STATS_F32 : PW_STATS_F64;
+      const int sgrid = (int)std::min<int64_t>((rows + 255) / 256, (int64_t)ctx.num_cus * 4);
+      if (pl.string) {
+        auto cand = make_device_buffer((size_t)sgrid * 16 + 16, ctx.device);
+        stats_keep.push_back(cand);
+        sp.cand = (long long*)cand->ptr;
+        check_hip(pw_launch_stats(sp, sgrid, ctx.stream), "launch pw_stats_kernel");
+        sp.n_cand = sgrid;
+        check_hip(pw_launch_stats(sp, 1, ctx.stream), "launch pw_stats_kernel (candidates)");
+      } else check_hip(pw_launch_stats(sp, sgrid, ctx.stream), "launch pw_stats_kernel");
+    }
     pl.needs_scan = rows > 0 && (pl.string || has_validity || pl.boolean);
     if (pl.needs_scan) {
       pl.block_sums = make_device_buffer((size_t)n_blocks * 8 + 16, ctx.device);
       e.block_sums = (unsigned long long*)pl.block_sums->ptr;
       check_hip(pw_launch_scan(e, ctx.stream), "launch pw_counts_kernel / pw_scan_kernel");
+      if (n_pages > 1 && !pl.boolean) {   // (a nullable Boolean column stays one page: its values are bit-packed without gaps)
+        pl.prefix.resize((size_t)n_blocks);
+        check_hip(hipMemcpyAsync(pl.prefix.data(), pl.block_sums->ptr, (size_t)n_blocks * 8, hipMemcpyDeviceToHost, ctx.stream), "read back block prefix");
+      }
     }
   }
   std::vector<unsigned long long> h_tot(nc + 1, 0);
   check_hip(hipMemcpyAsync(h_tot.data(), totals->ptr, 8 * nc, hipMemcpyDeviceToHost, ctx.stream), "read back");
+  if (nc) check_hip(hipMemcpyAsync(h_stats.data(), d_stats->ptr, 24 * nc, hipMemcpyDeviceToHost, ctx.stream), "read back statistics");
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+  for (size_t ci = 0; ci < nc; ++ci) {
+    const Column& c = rec.cols[ci];
+    ColumnPlan& pl = plan[ci];
+    const long long mn = h_stats[3 * ci], mx = h_stats[3 * ci + 1], cnt = h_stats[3 * ci + 2];
+    if (rows == 0 || cnt == 0) continue;   // all null (or all NaN): no min / max
+    auto raw = [](const void* v, size_t n) { return std::string((const char*)v, n); };
+    if (pl.string) {
+      if (mn < 0 || mx < 0) continue;
+      std::string* dst[2] = {&pl.min_value, &pl.max_value};
+      const long long row[2] = {mn, mx};
+      bool ok = true;
+      for (int k = 0; k < 2 && ok; ++k) {
+        int32_t o[2];
+        check_hip(hipMemcpy(o, (const int32_t*)c.values0() + row[k], 8, hipMemcpyDeviceToHost), "statistics: offsets");
+        const int64_t len = (int64_t)o[1] - o[0];
+        if (len > 4096) { ok = false; break; }   // (a reader gains nothing from a page-sized bound)
+        dst[k]->resize((size_t)len);
+        if (len) check_hip(hipMemcpy(&(*dst[k])[0], c.data + o[0], (size_t)len, hipMemcpyDeviceToHost), "statistics: bytes");
+      }
+      pl.has_minmax = ok;
+      continue;
+    }
+    auto unkey32 = [](long long k) { int32_t b = (int32_t)k; return (int32_t)(b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1)); };
+    auto unkey64 = [](long long k) { return (long long)(k ^ (long long)(((unsigned long long)(k >> 63)) >> 1)); };
+    switch (c.type) {
+      case T_I32: { int32_t a = (int32_t)mn, b = (int32_t)mx; pl.min_value = raw(&a, 4); pl.max_value = raw(&b, 4); } break;
+      case T_I64: pl.min_value = raw(&mn, 8); pl.max_value = raw(&mx, 8); break;
+      case T_F32: {   // the parquet writers' zero rule: a zero minimum is written as -0.0, a zero maximum as +0.0
+        int32_t a = unkey32(mn), b = unkey32(mx);
+        if ((a & 0x7fffffff) == 0) a = (int32_t)0x80000000; if ((b & 0x7fffffff) == 0) b = 0;
+        pl.min_value = raw(&a, 4); pl.max_value = raw(&b, 4); } break;
+      case T_F64: {
+        long long a = unkey64(mn), b = unkey64(mx);
+        if ((a & 0x7fffffffffffffffLL) == 0) a = (long long)0x8000000000000000ULL; if ((b & 0x7fffffffffffffffLL) == 0) b = 0;
+        pl.min_value = raw(&a, 8); pl.max_value = raw(&b, 8); } break;
+      default: { uint8_t a = (uint8_t)mn, b = (uint8_t)mx; pl.min_value = raw(&a, 1); pl.max_value = raw(&b, 1); } break;   // Boolean
+    }
+    pl.has_minmax = true;
+  }
 
   // ---- phase 2: value streams and level bitmaps in HBM ---------------------------------------------------------------
   for (size_t ci = 0; ci < nc; ++ci) {
@@ -143,49 +234,76 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
         if (e.validity) pl.null_count = rows - nv;
       }
     }
-    // definition levels (optional columns): bit width 1
-    if (pl.optional) {
-      std::vector<uint8_t> run;
-      auto varint = [&](uint64_t v) { while (v >= 0x80) { run.push_back((uint8_t)(v | 0x80)); v >>= 7; } run.push_back((uint8_t)v); };
-      int64_t dev_bytes = 0;
-      if (rows == 0) { /* no runs */ }
-      else if (e.validity) {   // one bit-packed run: the validity bits from bit 0, LSB first
-        const int64_t groups = (rows + 7) / 8;
-        varint(((uint64_t)groups << 1) | 1u);
-        dev_bytes = groups;
-        if ((c.offset & 7) == 0) pl.levels_dev = c.validity + (c.offset >> 3);
-        else {
-          auto vb = make_device_buffer((size_t)((rows + 63) / 64) * 8 + 16, ctx.device);
-          PwParams b = e; b.out = (uint8_t*)vb->ptr;
-          check_hip(pw_launch_shift_bits(b, grid, ctx.stream), "launch pw_shift_bits_kernel");
-          pl.keep.push_back(vb);
-          pl.levels_dev = (const uint8_t*)vb->ptr;
-        }
-      } else { varint((uint64_t)rows << 1); run.push_back(1); }   // one RLE run: `rows` times level 1
-      const uint32_t len = (uint32_t)(run.size() + dev_bytes);
-      pl.levels.resize(4); memcpy(pl.levels.data(), &len, 4);
-      pl.levels.insert(pl.levels.end(), run.begin(), run.end());
-      pl.levels_dev_bytes = dev_bytes;
+    // definition levels (optional columns), bit width 1: the validity bits from bit 0, LSB first (cut per page below)
+    if (pl.optional && rows > 0 && e.validity) {
+      if ((c.offset & 7) == 0) pl.levels_dev = c.validity + (c.offset >> 3);
+      else {
+        auto vb = make_device_buffer((size_t)((rows + 63) / 64) * 8 + 16, ctx.device);
+        PwParams b = e; b.out = (uint8_t*)vb->ptr;
+        check_hip(pw_launch_shift_bits(b, grid, ctx.stream), "launch pw_shift_bits_kernel");
+        pl.keep.push_back(vb);
+        pl.levels_dev = (const uint8_t*)vb->ptr;
+      }
     }
   }
 
-  // ---- the file image: PAR1, column chunks (page header + levels + values), footer, footer length, PAR1 ----------------
+  // ---- the file image: PAR1, column chunks (pages: header + levels + values), footer, footer length, PAR1 -----------------
   struct ChunkMeta { int64_t page_at, total; };
   std::vector<ChunkMeta> meta(nc);
-  std::vector<std::vector<uint8_t>> headers(nc);
+  std::vector<std::vector<PagePlan>> pages(nc);
   int64_t at = 4;
   for (size_t ci = 0; ci < nc; ++ci) {
+    const Column& c = rec.cols[ci];
     ColumnPlan& pl = plan[ci];
-    const int64_t payload = (int64_t)pl.levels.size() + pl.levels_dev_bytes + pl.stream_bytes;
-    ThriftOut t;
-    t.i32(1, PQ_DATA_PAGE); t.i32(2, payload); t.i32(3, payload);
-    t.begin_struct(5);
-    t.i32(1, rows); t.i32(2, PQ_PLAIN); t.i32(3, PQ_RLE); t.i32(4, PQ_RLE);
-    t.end_struct();
-    t.byte(0);
-    headers[ci] = std::move(t.o);
-    meta[ci] = {at, (int64_t)headers[ci].size() + payload};
-    at += meta[ci].total;
+    // Boolean values are bit-packed: a page may start inside a byte unless every row has a value and pages hold 8 k rows
+    const bool paged = n_pages > 1 && !(pl.boolean && pl.has_validity);
+    const int64_t np = paged ? n_pages : 1;
+    int64_t total = 0;
+    for (int64_t k = 0; k < np; ++k) {
+      PagePlan pg;
+      const int64_t r0 = paged ? k * page_rows : 0;
+      pg.rows = paged ? std::min(page_rows, rows - r0) : rows;
+      // the page's slice of the value stream
+      if (pl.stream_bytes > 0) {
+        int64_t b0, b1;
+        if (!paged) { b0 = 0; b1 = pl.stream_bytes; }
+        else if (pl.boolean) { b0 = r0 / 8; b1 = (r0 + pg.rows + 7) / 8; }
+        else if (!pl.needs_scan) { b0 = r0 * (int64_t)c.width; b1 = (r0 + pg.rows) * (int64_t)c.width; }
+        else {
+          b0 = (int64_t)pl.prefix[(size_t)(r0 / PW_BLOCK_ROWS_HOST)];
+          b1 = k + 1 < np ? (int64_t)pl.prefix[(size_t)((r0 + pg.rows) / PW_BLOCK_ROWS_HOST)] : pl.stream_bytes;
+        }
+        pg.stream = (const uint8_t*)pl.stream + b0; pg.stream_bytes = b1 - b0;
+      }
+      // the level section: [u32 length][one run]
+      std::vector<uint8_t> lv;
+      if (pl.optional) {
+        std::vector<uint8_t> run;
+        auto varint = [&](uint64_t v) { while (v >= 0x80) { run.push_back((uint8_t)(v | 0x80)); v >>= 7; } run.push_back((uint8_t)v); };
+        if (pg.rows == 0) { /* no runs */ }
+        else if (pl.levels_dev) {   // one bit-packed run of ceil(rows / 8) groups
+          const int64_t groups = (pg.rows + 7) / 8;
+          varint(((uint64_t)groups << 1) | 1u);
+          pg.levels_dev = pl.levels_dev + r0 / 8; pg.levels_dev_bytes = groups;
+        } else { varint((uint64_t)pg.rows << 1); run.push_back(1); }   // one RLE run: `rows` times level 1
+        const uint32_t len = (uint32_t)(run.size() + pg.levels_dev_bytes);
+        lv.resize(4); memcpy(lv.data(), &len, 4);
+        lv.insert(lv.end(), run.begin(), run.end());
+      }
+      const int64_t payload = (int64_t)lv.size() + pg.levels_dev_bytes + pg.stream_bytes;
+      ThriftOut t;
+      t.i32(1, PQ_DATA_PAGE); t.i32(2, payload); t.i32(3, payload);
+      t.begin_struct(5);
+      t.i32(1, pg.rows); t.i32(2, PQ_PLAIN); t.i32(3, PQ_RLE); t.i32(4, PQ_RLE);
+      t.end_struct();
+      t.byte(0);
+      pg.head = std::move(t.o);
+      pg.head.insert(pg.head.end(), lv.begin(), lv.end());
+      total += pg.total();
+      pages[ci].push_back(std::move(pg));
+    }
+    meta[ci] = {at, total};
+    at += total;
   }
   ThriftOut f;
   f.i32(1, 1);
@@ -212,7 +330,12 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
     f.list(2, ThriftOut::T_I32, 2); f.zigzag(PQ_PLAIN); f.zigzag(PQ_RLE);
     f.list(3, ThriftOut::T_BINARY, 1); f.varint(rec.cols[ci].name.size()); f.o.insert(f.o.end(), rec.cols[ci].name.begin(), rec.cols[ci].name.end());
     f.i32(4, 0); f.i64(5, rows); f.i64(6, meta[ci].total); f.i64(7, meta[ci].total); f.i64(9, meta[ci].page_at);
-    if (pl.null_count >= 0) { f.begin_struct(12); f.i64(3, pl.null_count); f.end_struct(); }
+    if (pl.null_count >= 0 || pl.has_minmax) {
+      f.begin_struct(12);
+      if (pl.null_count >= 0) f.i64(3, pl.null_count);
+      if (pl.has_minmax) { f.str(5, pl.max_value); f.str(6, pl.min_value); }
+      f.end_struct();
+    }
     f.end_struct();
     f.end_struct();
     total_bytes += meta[ci].total;
@@ -220,6 +343,9 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   f.i64(2, total_bytes); f.i64(3, rows);
   f.end_struct();
   f.str(6, "chapterhouseqe_amd (MI355X page encoder)");
+  // column_orders: TypeDefinedOrder for every column -- without it readers must ignore min_value / max_value
+  f.list(7, ThriftOut::T_STRUCT, nc);
+  for (size_t ci = 0; ci < nc; ++ci) { f.begin_element(); f.begin_struct(1); f.end_struct(); f.end_struct(); }
   f.byte(0);
   const int64_t file_len = at + (int64_t)f.o.size() + 8;
 
@@ -229,12 +355,12 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   uint8_t* out = (uint8_t*)img.bytes->ptr;
   memcpy(out, "PAR1", 4);
   for (size_t ci = 0; ci < nc; ++ci) {
-    const ColumnPlan& pl = plan[ci];
     int64_t p = meta[ci].page_at;
-    memcpy(out + p, headers[ci].data(), headers[ci].size()); p += (int64_t)headers[ci].size();
-    if (!pl.levels.empty()) { memcpy(out + p, pl.levels.data(), pl.levels.size()); p += (int64_t)pl.levels.size(); }
-    if (pl.levels_dev_bytes) { check_hip(hipMemcpyAsync(out + p, pl.levels_dev, (size_t)pl.levels_dev_bytes, hipMemcpyDeviceToHost, ctx.stream), "copy levels"); p += pl.levels_dev_bytes; }
-    if (pl.stream_bytes) check_hip(hipMemcpyAsync(out + p, pl.stream, (size_t)pl.stream_bytes, hipMemcpyDeviceToHost, ctx.stream), "copy values");
+    for (const PagePlan& pg : pages[ci]) {
+      memcpy(out + p, pg.head.data(), pg.head.size()); p += (int64_t)pg.head.size();
+      if (pg.levels_dev_bytes) { check_hip(hipMemcpyAsync(out + p, pg.levels_dev, (size_t)pg.levels_dev_bytes, hipMemcpyDeviceToHost, ctx.stream), "copy levels"); p += pg.levels_dev_bytes; }
+      if (pg.stream_bytes) { check_hip(hipMemcpyAsync(out + p, pg.stream, (size_t)pg.stream_bytes, hipMemcpyDeviceToHost, ctx.stream), "copy values"); p += pg.stream_bytes; }
+    }
   }
   memcpy(out + at, f.o.data(), f.o.size());
   const uint32_t flen = (uint32_t)f.o.size();

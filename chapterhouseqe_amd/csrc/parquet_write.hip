@@ -149,6 +149,88 @@ __global__ __launch_bounds__(256) void pw_shift_bits_kernel(const PwParams p) {
   }
 }
 
+// ---- chunk statistics: min / max ------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ bool stats_valid(const PwStatsParams& p, int64_t r) {
+  if (!p.validity) return true;
+  const int64_t b = p.bit_offset + r;
+  return (p.validity[b >> 3] >> (b & 7)) & 1;
+}
+// unsigned byte-lexicographic a < b (Parquet's order for BYTE_ARRAY / UTF8)
+__device__ bool utf8_less(const PwStatsParams& p, int64_t a, int64_t b) {
+  const int32_t ao = p.offsets[a], bo = p.offsets[b];
+  const int32_t al = p.offsets[a + 1] - ao, bl = p.offsets[b + 1] - bo;
+  const int32_t n = al < bl ? al : bl;
+  const uint8_t* pa = p.data + ao; const uint8_t* pb = p.data + bo;
+  for (int32_t i = 0; i < n; ++i) { if (pa[i] != pb[i]) return pa[i] < pb[i]; }
+  return al < bl;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void pw_stats_kernel(const PwStatsParams p) {
+  __shared__ long long s_min[4], s_max[4], s_cnt[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  long long mn = INT64_MAX, mx = INT64_MIN, cnt = 0;
+  if (p.kind == PW_STATS_UTF8) {
+    // candidates are rows (-1: none); the second launch (n_cand > 0) reduces the first launch's per-block candidates
+    long long rmin = -1, rmax = -1;
+    auto take = [&](long long r) {
+      if (r < 0) return;
+      if (rmin < 0 || utf8_less(p, r, rmin)) rmin = r;
+      if (rmax < 0 || utf8_less(p, rmax, r)) rmax = r;
+    };
+    if (p.n_cand > 0) { for (int i = threadIdx.x; i < 2 * p.n_cand; i += blockDim.x) take(p.cand[i]); }
+    else for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p.n_rows; r += stride) if (stats_valid(p, r)) { take(r); ++cnt; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long omin = __shfl_xor(rmin, o, 64), omax = __shfl_xor(rmax, o, 64);
+      if (omin >= 0 && (rmin < 0 || utf8_less(p, omin, rmin))) rmin = omin;
+      if (omax >= 0 && (rmax < 0 || utf8_less(p, rmax, omax))) rmax = omax;
+      cnt += __shfl_xor(cnt, o, 64);
+    }
+    if (lane == 0) { s_min[wv] = rmin; s_max[wv] = rmax; s_cnt[wv] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+        if (s_min[w] >= 0 && (rmin < 0 || utf8_less(p, s_min[w], rmin))) rmin = s_min[w];
+        if (s_max[w] >= 0 && (rmax < 0 || utf8_less(p, rmax, s_max[w]))) rmax = s_max[w];
+        cnt += s_cnt[w];
+      }
+      if (p.n_cand > 0) { p.out[0] = rmin; p.out[1] = rmax; }
+      else { p.cand[2 * blockIdx.x] = rmin; p.cand[2 * blockIdx.x + 1] = rmax; if (cnt) atomicAdd((unsigned long long*)&p.out[2], (unsigned long long)cnt); }
+    }
+    return;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p.n_rows; r += stride) {
+    if (!stats_valid(p, r)) continue;
+    long long k;
+    switch (p.kind) {
+      case PW_STATS_I32: k = ((const int32_t*)p.values)[r]; break;
+      case PW_STATS_I64: k = ((const long long*)p.values)[r]; break;
+      case PW_STATS_F32: { const float f = ((const float*)p.values)[r]; if (f != f) continue;   // NaNs take no part (parquet-rs, parquet-cpp)
+                           const int32_t b = __float_as_int(f); k = b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1); } break;
+      case PW_STATS_F64: { const double f = ((const double*)p.values)[r]; if (f != f) continue;
+                           const long long b = __double_as_longlong(f); k = b ^ (long long)(((unsigned long long)(b >> 63)) >> 1); } break;
+      default: k = p.values[r]; break;
+    }
+    mn = k < mn ? k : mn; mx = k > mx ? k : mx; ++cnt;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long a = __shfl_xor(mn, o, 64), b = __shfl_xor(mx, o, 64);
+    mn = a < mn ? a : mn; mx = b > mx ? b : mx; cnt += __shfl_xor(cnt, o, 64);
+  }
+  if (lane == 0) { s_min[wv] = mn; s_max[wv] = mx; s_cnt[wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { mn = s_min[w] < mn ? s_min[w] : mn; mx = s_max[w] > mx ? s_max[w] : mx; cnt += s_cnt[w]; }
+    if (cnt) { atomicMin(&p.out[0], mn); atomicMax(&p.out[1], mx); atomicAdd((unsigned long long*)&p.out[2], (unsigned long long)cnt); }
+  }
+}
+hipError_t pw_launch_stats(const PwStatsParams& p, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(pw_stats_kernel, dim3(p.n_cand > 0 ? 1 : grid), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
 hipError_t pw_launch_scan(const PwParams& p, hipStream_t s) {
   hipLaunchKernelGGL(pw_counts_kernel, dim3((unsigned)p.n_blocks), dim3(256), 0, s, p);
   hipLaunchKernelGGL(pw_scan_kernel, dim3(1), dim3(256), 0, s, p);

@@ -277,6 +277,72 @@ def test_written_files_are_read_back_by_pyarrow_and_by_the_scan(ctx):
             assert mine.equals(rec)
 
 
+def test_written_chunks_carry_the_statistics_a_cpu_writer_records(ctx):
+    """min / max / null_count of every column chunk equal what pyarrow's writer records for the same table (floats: NaNs
+    take no part, a zero minimum is -0.0 and a zero maximum +0.0; strings: unsigned byte order)"""
+    rng = np.random.default_rng(5)
+    n = 20_000
+    f32 = (rng.standard_normal(n) * 50).astype(np.float32)
+    f32[::97] = np.nan; f32[5] = 0.0; f32[6] = -0.0
+    zeros = np.zeros(n, dtype=np.float64); zeros[::2] = -0.0
+    words = np.array(["", "a", "ab", "zeta", "Zulu", "\u00e9t\u00e9", "\U0001F600", "a" * 300])
+    cases = [pa.table({
+        "i32": pa.array(rng.integers(-2**31, 2**31, n).astype(np.int32), mask=rng.random(n) < 0.1),
+        "i64": pa.array(rng.integers(-2**62, 2**62, n).astype(np.int64)),
+        "f32": pa.array(f32, mask=rng.random(n) < 0.05),
+        "f64": pa.array(rng.standard_normal(n) * 1e300),
+        "z": pa.array(zeros),
+        "b": pa.array(rng.integers(0, 2, n).astype(bool), mask=rng.random(n) < 0.3),
+        "t": pa.array(np.ones(n, dtype=bool)),
+        "s": pa.array(words[rng.integers(0, len(words), n)], type=pa.utf8(), mask=rng.random(n) < 0.2),
+        "nulls": pa.array([None] * n, type=pa.int32()),
+        "nans": pa.array(np.full(n, np.nan, dtype=np.float32)),
+    }), sample_table(4097, seed=3, nulls=True, strings="mixed"), sample_table(1, seed=4, nulls=False)]
+    for t in cases:
+        rec = t.to_batches()[0]
+        raw = chq.record_to_parquet(chq.DeviceRecordBatch.from_host(rec, ctx=ctx), ctx=ctx)
+        want_raw = io.BytesIO()
+        pq.write_table(t, want_raw, use_dictionary=False, compression="NONE")
+        got_md = pq.ParquetFile(io.BytesIO(raw)).metadata.row_group(0)
+        want_md = pq.ParquetFile(io.BytesIO(want_raw.getvalue())).metadata.row_group(0)
+        for i, f in enumerate(rec.schema):
+            g, w = got_md.column(i).statistics, want_md.column(i).statistics
+            assert g is not None and g.null_count == w.null_count == rec.column(i).null_count, f.name
+            assert g.has_min_max == w.has_min_max, (f.name, g.has_min_max, w.has_min_max)
+            if w.has_min_max:
+                same = lambda a, b: (a == b) and (not isinstance(a, float) or np.signbit(a) == np.signbit(b))
+                assert same(g.min, w.min) and same(g.max, w.max), (f.name, g.min, w.min, g.max, w.max)
+        from .helpers import batches_identical
+        assert batches_identical(pq.read_table(io.BytesIO(raw)).to_batches()[0], rec)   # (bit-exact: NaNs included)
+
+
+def test_chunks_are_cut_into_pages(ctx):
+    """several data pages per chunk (4 096-row granularity, at most 64 per chunk): every column kind, nulls, slices at odd
+    offsets; pyarrow and the scan read the same table back, and the page count is what the option asks for"""
+    from .helpers import batches_identical
+    c = chq.Context(0)
+    for page_rows, n, want_pages in [(4096, 4096, 1), (4096, 4097, 2), (4096, 50_000, 13), (8192, 300_001, 37), (65_536, 300_001, 5),
+                                     (4096, 1_000_000, 62)]:   # 245 pages asked -> capped: 64 pages of ceil(n / 64) rows, rounded up to 4 096
+        c.set_option("parquet_page_rows", page_rows)
+        for nulls in (False, True):
+            t = sample_table(n, seed=n + page_rows, nulls=nulls, strings="mixed")
+            rec = t.to_batches()[0] if n < 60_000 else pa.Table.from_batches(t.to_batches()).combine_chunks().to_batches()[0]
+            for source in (chq.DeviceRecordBatch.from_host(rec, ctx=c), rec.slice(3, n - 5)):
+                raw = chq.record_to_parquet(source, ctx=c)
+                want = source.to_host() if hasattr(source, "to_host") else source
+                assert batches_identical(pq.read_table(io.BytesIO(raw)).combine_chunks().to_batches()[0], want)
+                f = chq.ParquetFile(raw)
+                assert batches_identical(f.read_row_group(0, ctx=c).to_host(), want)
+                rows = want.num_rows
+                pages = {line.split()[1]: int(line.split()[-1]) for line in f.describe().splitlines() if line.startswith("chunk ")}
+                expect = want_pages if rows == n else None
+                for i, fld in enumerate(want.schema):
+                    one_page = pa.types.is_boolean(fld.type) and want.column(i).null_count > 0   # bit-packed values without gaps
+                    if expect is not None:
+                        assert pages[str(i)] == (1 if one_page else expect), (fld.name, pages, expect)
+    c.close()
+
+
 def test_sliced_batches_are_written_from_their_first_row(ctx):
     t = sample_table(5000, seed=77, nulls=True)
     for off, ln in [(1, 100), (3, 4000), (64, 4936), (4097, 500)]:
