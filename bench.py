@@ -443,7 +443,8 @@ def check_config5_outputs(torch, keep, outs, batch_index=0):
     assert torch.equal(odata[first: first + sel.numel()], sel)
 
 
-def config5_main(args, chq, torch, dist, rank, local_rank, world, dev, ctx):
+def config5_main(args, chq, torch, dist, rank, local_rank, world, dev, ctx, comm_dev=None):
+    comm_dev = comm_dev if comm_dev is not None else dev
     from chapterhouseqe_amd.sqlparse import parse_expr
     rows, total_rows, scaling = plan_rows(args, world, rank)
     batches, keep = build_config5_shard(chq, torch, dev, ctx, rows, args.batch_rows, rank)
@@ -485,7 +486,7 @@ def config5_main(args, chq, torch, dist, rank, local_rank, world, dev, ctx):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed, per_gpu, (rows_out_total, kernel_ns_sum, alg_sum) = reduce_timing(dist, torch, world, dev, elapsed, rows, args.steps, [rows_out, kernel_ns, alg])
+    elapsed, per_gpu, (rows_out_total, kernel_ns_sum, alg_sum) = reduce_timing(dist, torch, world, comm_dev, elapsed, rows, args.steps, [rows_out, kernel_ns, alg])
     gathered = None
     if args.gathered and world > 1:
         gathered = gather_to_rank0(chq, torch, dist, rank, world, dev, ctx, grp, expr)
@@ -567,22 +568,33 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the filter path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # CHQ_BENCH_REHEARSE=1: the N-rank code path on a box with ONE GPU (development boxes; tests/test_gpu_scale.py) -- every
+    # rank runs on device 0 and the ranks talk through gloo (RCCL refuses two ranks on one device).  Timings of such a run
+    # mean nothing (the ranks share the card); the row plan, the barriers, the reductions and the JSON line are the real ones.
+    rehearse = os.environ.get("CHQ_BENCH_REHEARSE") == "1" and world > 1
+    gpu_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(gpu_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import chapterhouseqe_amd as chq
     from chapterhouseqe_amd.sqlparse import parse_expr
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", gpu_index)
+    comm_dev = torch.device("cpu") if rehearse else dev   # where the reduced scalars live (gloo reduces host tensors)
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = chq.Context(local_rank, stream=stream)
+    ctx = chq.Context(gpu_index, stream=stream)
     ctx.set_option("time_kernels", 1)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
     if args.config == 5:
-        config5_main(args, chq, torch, dist, rank, local_rank, world, dev, ctx)
+        if rehearse and args.gathered:
+            raise SystemExit("--gathered needs RCCL: not available in the one-GPU rehearsal")
+        config5_main(args, chq, torch, dist, rank, local_rank, world, dev, ctx, comm_dev)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -612,7 +624,7 @@ def main():
 
     elapsed, kernel_ns, stats = time_config2(chq, torch, dist, world, ctx, cols, n, expr, aliases, args.steps, args.warmup)
     rows_out = stats["rows_out"]
-    elapsed, per_gpu, (rows_out_total, kernel_ns_sum) = reduce_timing(dist, torch, world, dev, elapsed, n, args.steps, [rows_out, kernel_ns])
+    elapsed, per_gpu, (rows_out_total, kernel_ns_sum) = reduce_timing(dist, torch, world, comm_dev, elapsed, n, args.steps, [rows_out, kernel_ns])
     kernel_ns = kernel_ns_sum // world
 
     # ---- N > 1, strong scaling: the weak-scaling run (every GPU its own `total_rows`-row shard) rides along -------------
@@ -622,7 +634,7 @@ def main():
         torch.cuda.empty_cache()
         wcols = make_config2_columns(torch, dev, total_rows, rank)
         w_elapsed, w_kns, w_stats = time_config2(chq, torch, dist, world, ctx, wcols, total_rows, expr, aliases, args.steps, args.warmup)
-        w_elapsed, w_per_gpu, (w_rows_out, w_kns_sum) = reduce_timing(dist, torch, world, dev, w_elapsed, total_rows, args.steps, [w_stats["rows_out"], w_kns])
+        w_elapsed, w_per_gpu, (w_rows_out, w_kns_sum) = reduce_timing(dist, torch, world, comm_dev, w_elapsed, total_rows, args.steps, [w_stats["rows_out"], w_kns])
         w_alg = w_stats["bytes_read_alg"] + w_stats["bytes_written_alg"]
         w_kms = w_kns_sum / world / args.steps / 1e6
         weak = {"scaling": "weak", "rows_per_gpu": total_rows, "value": total_rows * world * args.steps / w_elapsed, "unit": "rows/s",

@@ -128,6 +128,11 @@ struct PwStatsParams {
   int32_t n_cand; int32_t pad2; // Utf8, second launch: number of blocks of the first
 };
 hipError_t pw_launch_stats(const PwStatsParams& p, int grid, hipStream_t s);
+// pw_assemble_kernel: the file body is put together in HBM -- page headers (uploaded as one blob), level bytes and value
+// streams copied to their file offsets -- so that the image needs ONE device-to-host copy however many pages it has
+struct PwPiece { unsigned long long dst; const uint8_t* src; unsigned long long len; };
+struct PwAssembleParams { const PwPiece* pieces; uint8_t* image; unsigned long long seg; };   // seg: bytes per block (multiple of 16)
+hipError_t pw_launch_assemble(const PwAssembleParams& p, int n_pieces, int n_segs, hipStream_t s);
 constexpr int PW_BLOCK_ROWS_HOST = 4096;   // = PW_BLOCK_ROWS of parquet_write.hip
 hipError_t pw_launch_scan(const PwParams& p, hipStream_t s);
 hipError_t pw_launch_encode(const PwParams& p, hipStream_t s);

@@ -354,13 +354,37 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   img.len = file_len;
   uint8_t* out = (uint8_t*)img.bytes->ptr;
   memcpy(out, "PAR1", 4);
-  for (size_t ci = 0; ci < nc; ++ci) {
-    int64_t p = meta[ci].page_at;
-    for (const PagePlan& pg : pages[ci]) {
-      memcpy(out + p, pg.head.data(), pg.head.size()); p += (int64_t)pg.head.size();
-      if (pg.levels_dev_bytes) { check_hip(hipMemcpyAsync(out + p, pg.levels_dev, (size_t)pg.levels_dev_bytes, hipMemcpyDeviceToHost, ctx.stream), "copy levels"); p += pg.levels_dev_bytes; }
-      if (pg.stream_bytes) { check_hip(hipMemcpyAsync(out + p, pg.stream, (size_t)pg.stream_bytes, hipMemcpyDeviceToHost, ctx.stream), "copy values"); p += pg.stream_bytes; }
+  // The body [4, at) is assembled in HBM (page heads uploaded as one blob, levels and value streams copied to their file
+  // offsets by pw_assemble_kernel) and comes down in ONE copy: one copy per page part cost 6 ms for a 4 M-row batch in
+  // 62 pages per chunk, against 1.6 ms for the single-page form.
+  if (at > 4) {
+    size_t n_pieces = 0, blob_bytes = 0;
+    for (size_t ci = 0; ci < nc; ++ci) for (const PagePlan& pg : pages[ci]) { n_pieces += 1 + (pg.levels_dev_bytes > 0) + (pg.stream_bytes > 0); blob_bytes += pg.head.size(); }
+    const size_t pieces_bytes = (n_pieces * sizeof(PwPiece) + 63) & ~(size_t)63;
+    std::vector<uint8_t> up(pieces_bytes + blob_bytes);
+    auto d_up = make_device_buffer(up.size() + 64, ctx.device);
+    auto d_img = make_device_buffer((size_t)at + 64, ctx.device);
+    PwPiece* pc = (PwPiece*)up.data();
+    size_t k = 0, bo = pieces_bytes;
+    unsigned long long longest = 0;
+    for (size_t ci = 0; ci < nc; ++ci) {
+      int64_t p = meta[ci].page_at;
+      for (const PagePlan& pg : pages[ci]) {
+        memcpy(up.data() + bo, pg.head.data(), pg.head.size());
+        pc[k++] = PwPiece{(unsigned long long)p, (const uint8_t*)d_up->ptr + bo, (unsigned long long)pg.head.size()};
+        bo += pg.head.size(); p += (int64_t)pg.head.size();
+        if (pg.levels_dev_bytes) { pc[k++] = PwPiece{(unsigned long long)p, pg.levels_dev, (unsigned long long)pg.levels_dev_bytes}; p += pg.levels_dev_bytes; }
+        if (pg.stream_bytes) { pc[k++] = PwPiece{(unsigned long long)p, pg.stream, (unsigned long long)pg.stream_bytes}; p += pg.stream_bytes; }
+      }
     }
+    for (size_t i = 0; i < n_pieces; ++i) longest = std::max(longest, pc[i].len);
+    unsigned long long seg = 256 * 1024;
+    while ((longest + seg - 1) / seg > 65535) seg *= 2;
+    check_hip(hipMemcpyAsync(d_up->ptr, up.data(), up.size(), hipMemcpyHostToDevice, ctx.stream), "upload page heads");
+    PwAssembleParams ap{(const PwPiece*)d_up->ptr, (uint8_t*)d_img->ptr, seg};
+    check_hip(pw_launch_assemble(ap, (int)n_pieces, (int)std::max<unsigned long long>(1, (longest + seg - 1) / seg), ctx.stream), "launch pw_assemble_kernel");
+    check_hip(hipMemcpyAsync(out + 4, (const uint8_t*)d_img->ptr + 4, (size_t)at - 4, hipMemcpyDeviceToHost, ctx.stream), "copy the file body");
+    check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");   // (`up` and the device blocks are released below)
   }
   memcpy(out + at, f.o.data(), f.o.size());
   const uint32_t flen = (uint32_t)f.o.size();

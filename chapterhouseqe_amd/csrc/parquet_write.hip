@@ -231,6 +231,25 @@ hipError_t pw_launch_stats(const PwStatsParams& p, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+// one block per (piece, segment): 16-byte copies between arbitrarily aligned addresses (page headers have odd lengths)
+__global__ __launch_bounds__(256) void pw_assemble_kernel(const PwAssembleParams p) {
+  const PwPiece pc = p.pieces[blockIdx.x];
+  const unsigned long long b0 = (unsigned long long)blockIdx.y * p.seg;
+  if (b0 >= pc.len) return;
+  const unsigned long long b1 = b0 + p.seg < pc.len ? b0 + p.seg : pc.len;
+  uint8_t* dst = p.image + pc.dst;
+  for (unsigned long long b = b0 + (unsigned long long)threadIdx.x * 16; b + 16 <= b1; b += 256 * 16) {
+    uint4 w; __builtin_memcpy(&w, pc.src + b, 16); __builtin_memcpy(dst + b, &w, 16);
+  }
+  const unsigned long long tail = b0 + ((b1 - b0) & ~15ull);
+  for (unsigned long long b = tail + threadIdx.x; b < b1; b += 256) dst[b] = pc.src[b];
+}
+hipError_t pw_launch_assemble(const PwAssembleParams& p, int n_pieces, int n_segs, hipStream_t s) {
+  if (n_pieces <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pw_assemble_kernel, dim3((unsigned)n_pieces, (unsigned)n_segs), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
 hipError_t pw_launch_scan(const PwParams& p, hipStream_t s) {
   hipLaunchKernelGGL(pw_counts_kernel, dim3((unsigned)p.n_blocks), dim3(256), 0, s, p);
   hipLaunchKernelGGL(pw_scan_kernel, dim3(1), dim3(256), 0, s, p);

@@ -209,3 +209,37 @@ def test_config5_one_rank_shard_at_full_size():
         o.release()
     grp.release()
     ctx.close()
+
+
+@pytest.mark.parametrize("extra,rows_per_gpu", [(["--rows", "120000001"], None), (["--scaling", "weak", "--rows", "30000000"], 30_000_000),
+                                                (["--config", "5", "--rows", "60000000", "--batch-rows", "25000000"], 60_000_000)])
+def test_bench_n_rank_path_rehearsed_on_one_gpu(extra, rows_per_gpu):
+    """`bench.py --gpus 3` end to end on this box's single GPU (CHQ_BENCH_REHEARSE=1: all ranks on device 0, gloo between them):
+    the code path the driver runs on the 8-GPU node -- self-launch through torch.distributed.run, the row plan (strong:
+    120 000 001 rows split 40 000 001 / 40 000 000 / 40 000 000), barriers, MAX / SUM reductions, the weak run riding along,
+    config 5 per-rank shards -- with the real kernels.  Timings of a shared card mean nothing and are not checked."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CHQ_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--validate-rows", "200000"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = lines[0]
+    assert j["n_gpus"] == 3 and j["steps"] == 3 and j["value"] > 0 and len(j["config"]["per_gpu_rows_per_s"]) == 3
+    if "--config" in extra:
+        assert j["scaling"] == "weak" and j["config"]["rows_per_gpu"] == rows_per_gpu and j["config"]["rows_total"] == 3 * rows_per_gpu
+        assert abs(j["config"]["selectivity"] - 0.5) < 1e-6
+    elif "weak" in extra:
+        assert j["scaling"] == "weak" and j["config"]["rows_per_gpu"] == rows_per_gpu and j["config"]["rows_total"] == 3 * rows_per_gpu
+        assert "extra" not in j or "weak" not in j["extra"]
+    else:
+        assert j["scaling"] == "strong" and j["config"]["rows_total"] == 120_000_001 and j["config"]["rows_per_gpu"] == 40_000_001
+        assert j["extra"]["weak"]["rows_per_gpu"] == 120_000_001 and j["extra"]["weak"]["value"] > 0
+        assert 0.89 < j["config"]["rows_out_total"] / 120_000_001 < 0.91     # value2 > 10.0 keeps ~90 %
+        assert j["roofline"]["traffic"] is None                              # (the PMC file was measured on 1e9 rows per GPU)
