@@ -4,6 +4,7 @@
 // operator_handler/operators/record_utils of the reference).
 #include "engine.hpp"
 #include <deque>
+#include <exception>
 #include <atomic>
 #include <mutex>
 #include <condition_variable>
@@ -106,6 +107,11 @@ void HostPool::set_limit(size_t bytes) {
 
 Buffer::~Buffer() {
   if (!ptr) return;
+  // A block released while an exception unwinds the call may still be the source or target of work queued on the context's
+  // streams (staged uploads ahead of a typing error, copies behind a kernel that reported a data error): the pools are
+  // process-wide, and another context -- another stream -- would get it next.  The fuzz met exactly that: a call's first
+  // output columns overwritten by the late upload of an earlier, failed call.  Errors are the slow path: wait for the device.
+  if (std::uncaught_exceptions() > 0) (void)hipDeviceSynchronize();
   if (device) DevicePool::instance().free(ptr, cap, device_id); else HostPool::instance().free(ptr, cap);
 }
 BufferPtr make_device_buffer(size_t bytes, int device) {
@@ -630,9 +636,20 @@ u64* dev_status(Context& ctx) { return (u64*)((uint8_t*)ctx.small->ptr + kHeader
 bool encode_fast_uops(ProgramBlock& pb, const Lowered& lw, const Batch& rec) {
   if (lw.wide || lw.num_temps > 0 || !lw.strs.empty() || lw.prog.empty()) return false;
   auto is32 = [](int t) { return t == T_I32 || t == T_U32 || t == T_F32; };
+  bool nullable_ref = false;
   for (int ci : lw.refs) {
     const Column& c = rec.cols[ci];
-    if (!is32(c.type) || (c.validity && c.null_count != 0)) return false;
+    if (!is32(c.type)) return false;
+    nullable_ref |= c.validity && c.null_count != 0;
+  }
+  if (nullable_ref) {
+    // columns WITH nulls: only `column <cmp> literal` (LOAD col; CMP const) -- the predicate of most sample queries, and Parquet
+    // `optional` columns with real nulls are the normal case off read_files -- keeps the fast evaluators (they AND the column's
+    // validity into the result; their boolean temporaries carry none, so anything longer takes the generic interpreter)
+    const bool cmp_const = lw.prog.size() == 2 && lw.refs.size() == 1 && lw.prog[0].op == OP_LOAD && lw.prog[0].src_kind == SRC_COL &&
+                           lw.prog[0].src_type == lw.prog[0].type && lw.prog[1].op >= OP_EQ && lw.prog[1].op <= OP_GE &&
+                           lw.prog[1].src_kind == SRC_CONST && lw.prog[1].type == lw.prog[0].type;
+    if (!cmp_const) return false;
   }
   for (size_t i = 0; i < lw.prog.size(); ++i) {
     const Instr& in = pb.prog[i];   // (never modified: incomplete waves run the same program through the generic interpreter)

@@ -421,6 +421,21 @@ struct Interp {
     }
   }
 
+  // validity flags of column-ref `ref_idx` for this wave's slots (all active slots when the column has no bitmap)
+  __device__ __forceinline__ uint32_t col_valid(const ProgramBlock& pb, int ref_idx) const {
+    const void* vb = pb.refs[ref_idx].validity;
+    int64_t voff = pb.refs[ref_idx].validity_bit_offset;
+    if constexpr (PARTIAL) {
+      if (ptr_row && pb.group_bits_at) {   // batch-group launch with bitmaps: this wave's batch has its own
+        const u64* ptr_bits = ptr_row + (pb.group_bits_at - 1);
+        vb = (const void*)ptr_bits[ref_idx];
+        voff = (int64_t)ptr_bits[pb.n_refs + ref_idx];
+      }
+      if (nact <= 0) return actv;          // (a wave past the end of its batch reads nothing)
+    }
+    return vb ? (fetch_flags(vb, voff) & actv) : actv;
+  }
+
   __device__ __forceinline__ void fetch_col(const ProgramBlock& pb, const ColRef& c, int ref_idx, uint32_t (&l)[R], uint32_t (&h)[RH], uint32_t& b, uint32_t& v) {
     b = 0;
     if constexpr (!PARTIAL) {
@@ -794,6 +809,12 @@ struct Interp {
       const unsigned opd = pb.fast_opd[pc];
       const uint32_t c = (uint32_t)in.imm;
       uint32_t tb = 0;
+      if (opd == FO_COL || opd == FO_COL_I2F || opd == FO_COL_U2F) {
+        // a column operand brings its validity (only `column <cmp> literal` programs reach this evaluator with a nullable
+        // column -- engine.cpp: encode_fast_uops -- i.e. LOAD col, CMP const: boolean temporaries carry no validity here)
+        const uint32_t cv = col_valid(pb, (int)in.src_idx);
+        validv = (pb.fast_op[pc] & 0x7fu) == FU_LD ? cv : (validv & cv);
+      }
       switch (opd) {   // ---- operand ----
         case FO_COL: fetch_raw(pb, in.src_idx, y); stash_put((int)in.src_idx, y); break;
         case FO_COL_I2F:
@@ -950,7 +971,7 @@ struct Interp {
     }
 #undef FAST_LOOPS
     bitsv = (negate ? ~r : r) & actv;
-    validv = actv;
+    validv = col_valid(pb, 0);   // (round 3: `column <cmp> literal` on a column WITH nulls keeps this path)
   }
 
   // ---- the program loop --------------------------------------------------------------------------
@@ -1701,8 +1722,14 @@ template <int BLOCK, int R, bool WIDE, int NUM_TEMPS, bool PARTIAL, bool FASTK>
 __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
   constexpr int64_t TILE = (int64_t)BLOCK * R;
   __shared__ TempLds<BLOCK, R, NUM_TEMPS> s_tmp;
+  // null counts are gathered per workgroup in LDS and added to the outputs' counters once, at the end: one global atomic
+  // per wave and tile put ~10^6 atomics on one address for a 10^9-row projection of a nullable column (9.6 ms for 400 M
+  // rows against 1.5 ms for the same projection of non-null columns)
+  __shared__ unsigned s_nulls[MAX_PROJ];   // (a workgroup sees fewer than 2^31 rows: batches are below that)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < MAX_PROJ) s_nulls[tid] = 0;
+  __syncthreads();
   for (int64_t tile = p.tile_begin + blockIdx.x; tile < p.tile_end; tile += gridDim.x) {
     Interp<BLOCK, R, WIDE, PARTIAL> it;
     it.set_rows(tile * TILE, p.nrows, lane, wv);
@@ -1740,12 +1767,16 @@ __global__ __launch_bounds__(BLOCK) void project_kernel(const ProjectParams p) {
           const u64 a = s.group_act(j);
           if (a) { if (lane == 0) po.validity[(s.w0 >> 6) + j] = v; nulls += __popcll(a & ~v); }
         }
-        if (nulls && lane == 0) atomicAdd(po.null_count, (u64)nulls);
+        if (nulls && lane == 0) atomicAdd(&s_nulls[out_idx], nulls);
       }
     };
     if constexpr (FASTK) it.run_fast(p.pb, p.err, dense_store);
     else it.run(p.pb, p.err, s_tmp.flags, s_tmp.num, dense_store);
     __syncthreads();   // temporaries in LDS are reused by the next tile
+  }
+  if (tid == 0) {
+#pragma unroll 1
+    for (int k = 0; k < p.n_proj; ++k) if (s_nulls[k]) atomicAdd(p.outs[k].null_count, (u64)s_nulls[k]);   // (uniform index: scalar loads of the argument block)
   }
 }
 
@@ -1771,15 +1802,21 @@ __global__ __launch_bounds__(BLOCK) void bit_compact_kernel(const BitCompactPara
     u64 lo64 = 0; u64 hi64 = 0; int total = shift0;   // shift0 leading zero bits belong to earlier rows
     bool head_shared = shift0 != 0;
     unsigned zeros = 0;
+    // lane j fetches slot j's selection word and input bits up front (see bit_compact_group_kernel)
+    u64 my_m = 0, my_in = 0;
+    if (lane < R) {
+      const u64 act = active_mask(w0 + 64 * lane, p.nrows);
+      if (act) {
+        my_m = p.sel_mask[(w0 >> 6) + lane] & act;
+        my_in = load_bits64(p.in_bits, p.in_bit_offset + w0 + 64 * lane, act);
+      }
+    }
 #pragma unroll 1
     for (int j = 0; j < R; ++j) {
-      const int64_t r0 = w0 + 64 * j;
-      const u64 act = active_mask(r0, p.nrows);
-      if (!act) break;
-      const u64 m = p.sel_mask[r0 >> 6] & act;
+      const u64 m = (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_m, j) | ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_m >> 32), j) << 32);
       const int cnt = __popcll(m);
-      if (cnt == 0) continue;
-      const u64 inb = load_bits64(p.in_bits, p.in_bit_offset + r0, act);
+      if (cnt == 0) continue;   // (nothing selected, or past the end)
+      const u64 inb = (u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_in, j) | ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_in >> 32), j) << 32);
       const int mybit = (int)((inb >> lane) & 1);
       const bool sel = (m >> lane) & 1;
       // compress: selected lane -> lane rank(m); unselected lanes take the remaining slots from the top

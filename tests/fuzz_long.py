@@ -114,6 +114,26 @@ def typed_expr(rng, rec, want_bool):
     return None
 
 
+def dump_case(rec, exp, got):
+    """small cases: the input and both results, bit patterns of the floats included (enough to replay the case by hand)"""
+    if rec.num_rows > 40:
+        return
+    def show(x):
+        try:
+            cols = x.columns if hasattr(x, "columns") else [x]
+            out = []
+            for c in cols:
+                if pa.types.is_floating(c.type):
+                    w = {16: np.uint16, 32: np.uint32, 64: np.uint64}[c.type.bit_width]
+                    out.append([None if v is None else hex(int(np.array([v], dtype=c.type.to_pandas_dtype()).view(w)[0])) for v in c.to_pylist()])
+                else:
+                    out.append(c.to_pylist())
+            return out
+        except Exception as e:   # noqa: BLE001
+            return f"<{e}>"
+    print(" input ", show(rec), "\n oracle", show(exp), "\n gpu   ", show(got), flush=True)
+
+
 def outcome(fn):
     try:
         return None, fn()
@@ -204,6 +224,7 @@ def main():
                 continue
             if not same:
                 print(f"VALUE MISMATCH [{kind}] n={rec.num_rows}: {sql}\n schema {rec.schema} aliases {al}", flush=True)
+                dump_case(rec, exp, got)
                 return 1
             continue
         if mode < 0.45:
@@ -326,6 +347,8 @@ def main():
             continue
         if not same:
             print(f"VALUE MISMATCH [{kind}] n={rec.num_rows}: {sql}", flush=True)
+            if kind != "group":
+                dump_case(rec, exp, got)
             if kind in ("filter", "project"):
                 print(explain_diff(got, exp))
             return 1

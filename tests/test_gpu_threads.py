@@ -58,3 +58,32 @@ def test_four_contexts_on_four_threads():
         t.join(timeout=300)
     assert not errors, errors
     assert all(not t.is_alive() for t in threads)
+
+
+def test_a_failed_call_does_not_leak_in_flight_work_into_the_pool():
+    """A call that fails after it has queued its uploads (a typing error is found after staging) releases its blocks while
+    the copies may still be in flight; the pools are process-wide, so the next call -- on ANOTHER context, i.e. another
+    stream -- gets those blocks as its outputs.  Round 3's fuzz met the corruption twice (first output columns of a small
+    filter overwritten); blocks released during unwinding now wait for the device (engine.cpp: Buffer::~Buffer)."""
+    import numpy as np
+    import pyarrow as pa
+    from chapterhouseqe_amd.sqlparse import parse_expr
+    from oracle import oracle as O
+    from .helpers import batches_identical
+    a, b = chq.Context(0), chq.Context(0)
+    n = 600_000
+    rng = np.random.default_rng(12)
+    rec = pa.RecordBatch.from_arrays([pa.array(rng.integers(0, 1000, n).astype(np.int64)), pa.array(rng.random(n)),
+                                      pa.array(rng.integers(0, 1000, n).astype(np.int64))], names=["x", "y", "z"])
+    other = pa.RecordBatch.from_arrays([pa.array(np.arange(n, dtype=np.int64)), pa.array(np.arange(n, dtype=np.float64)),
+                                        pa.array(np.arange(n, dtype=np.int64) * 3)], names=["x", "y", "z"])
+    al = [[], [], []]
+    bad, good = parse_expr("x + 1.5 > y"), parse_expr("x >= 0")        # Int64 + Float32: no common type (status 9); keeps every row
+    want = O.filter_record(other, al, good)
+    for it in range(150):
+        with pytest.raises(chq.ChqError) as e:
+            chq.filter_record(rec, al, bad, ctx=a)
+        assert e.value.code == 9
+        got = chq.filter_record(other, al, good, ctx=b)
+        assert batches_identical(got, want), f"iteration {it}"
+    a.close(); b.close()
