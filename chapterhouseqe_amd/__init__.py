@@ -9,8 +9,8 @@ from .record_utils import (ChqError, Context, DeviceRecordBatch, compute_value, 
                            filter_project_record, filter_record, filter_records, filter_records_coalesced,
                            get_record_table_aliases,
                            ipc_describe, plan_describe, project_record, record_from_ipc, record_to_ipc, RecordGroup,
-                           ParquetFile, scan_parquet, record_to_parquet)
+                           ParquetFile, scan_parquet, record_to_parquet, records_to_parquet)
 
 __all__ = ["sqlast", "sqlparse", "ChqError", "Context", "DeviceRecordBatch", "compute_value", "default_context",
            "filter_project_record", "filter_record", "filter_records", "filter_records_coalesced", "get_record_table_aliases", "plan_describe", "project_record",
-           "RecordGroup", "ipc_describe", "record_from_ipc", "record_to_ipc", "ParquetFile", "scan_parquet", "record_to_parquet"]
+           "RecordGroup", "ipc_describe", "record_from_ipc", "record_to_ipc", "ParquetFile", "scan_parquet", "record_to_parquet", "records_to_parquet"]

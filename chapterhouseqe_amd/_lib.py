@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "chq_record_copy_to_peer", "chq_record_to_ipc", "chq_record_from_ipc", "chq_ipc_describe",
     "chq_parquet_open", "chq_parquet_open_reader", "chq_parquet_num_columns", "chq_parquet_column_name", "chq_parquet_read_columns",
     "chq_parquet_close", "chq_parquet_num_row_groups", "chq_parquet_row_group_num_rows",
-    "chq_parquet_describe", "chq_parquet_read_row_group", "chq_parquet_read_row_groups", "chq_record_to_parquet",
+    "chq_parquet_describe", "chq_parquet_read_row_group", "chq_parquet_read_row_groups", "chq_record_to_parquet", "chq_records_to_parquet",
 ]
 
 
@@ -177,6 +177,7 @@ def lib():
         "chq_parquet_read_row_group": (ci, [vp, vp, C.c_int32, ci, PDA, PS]),
         "chq_parquet_read_row_groups": (ci, [vp, vp, C.c_int32, C.c_int32, ci, vp, vp]),
         "chq_record_to_parquet": (ci, [vp, PDA, PS, C.POINTER(ParquetImage)]),
+        "chq_records_to_parquet": (ci, [vp, ci, C.POINTER(PDA), PS, C.POINTER(ParquetImage)]),
     }
     for name, (res, args) in sig.items():
         try:

@@ -752,6 +752,24 @@ chq_status chq_record_to_parquet(chq_ctx* ctx, const ArrowDeviceArray* rec, cons
   });
 }
 
+chq_status chq_records_to_parquet(chq_ctx* ctx, int n_records, const ArrowDeviceArray* const* recs, const ArrowSchema* schema,
+                                  chq_parquet_image* out) {
+  if (!ctx) return CHQ_ERR_INVALID_HANDLE;
+  if (out) { out->data = nullptr; out->len = 0; out->release = nullptr; out->private_data = nullptr; }
+  return guarded(ctx, [&] {
+    require(out, "output image"); require(recs, "record batches");
+    if (n_records < 1) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "chq_records_to_parquet needs at least one record batch"};
+    check_hip(hipSetDevice(ctx->c.device), "hipSetDevice");
+    std::vector<Batch> in((size_t)n_records);
+    std::vector<const Batch*> ptrs((size_t)n_records);
+    for (int i = 0; i < n_records; ++i) { in[(size_t)i] = import_batch(recs[i], schema); ptrs[(size_t)i] = &in[(size_t)i]; }
+    auto* h = new ParquetImageHolder();
+    try { h->img = records_to_parquet(ctx->c, ptrs); } catch (...) { delete h; throw; }
+    out->data = (const uint8_t*)h->img.bytes->ptr; out->len = h->img.len;
+    out->release = release_parquet_image; out->private_data = h;
+  });
+}
+
 chq_status chq_record_to_host(chq_ctx* ctx, const ArrowDeviceArray* rec, const ArrowSchema* schema, ArrowDeviceArray* out,
                               ArrowSchema* out_schema) {
   if (!ctx) return CHQ_ERR_INVALID_HANDLE;

@@ -113,5 +113,7 @@ struct ParquetImage {
   int64_t len = 0;
 };
 ParquetImage record_to_parquet(Context& ctx, const Batch& rec);
+// several batches of one schema -> one file, one row group per batch
+ParquetImage records_to_parquet(Context& ctx, const std::vector<const Batch*>& recs);
 
 }  // namespace chq

@@ -74,14 +74,29 @@ struct PagePlan {
   int64_t total() const { return (int64_t)head.size() + levels_dev_bytes + stream_bytes; }
 };
 
-}  // namespace
+struct ChunkMeta { int64_t page_at, total; };
+// one row group of the file: the batch on the device, its columns' streams and pages, where its chunks lie in the file
+struct RowGroupPlan {
+  Batch rec;
+  int64_t rows = 0;
+  std::vector<ColumnPlan> plan;
+  std::vector<std::vector<PagePlan>> pages;
+  std::vector<ChunkMeta> meta;
+  std::vector<BufferPtr> keep;
+};
 
-ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
-  const Batch rec = to_device(ctx, in);
+// Streams, statistics and page layout of ONE batch as one row group whose first chunk starts at file offset `at` (advanced
+// past the row group's last page).
+RowGroupPlan plan_row_group(Context& ctx, const Batch& in, int64_t& at) {
+  RowGroupPlan rg;
+  rg.rec = to_device(ctx, in);
+  const Batch& rec = rg.rec;
   const int64_t rows = rec.nrows;
+  rg.rows = rows;
   if (rows >= (1ll << 31)) throw ChqError{CHQ_ERR_NOT_SUPPORTED, "parquet: a batch of " + std::to_string(rows) + " rows in one page"};
   const size_t nc = rec.cols.size();
-  std::vector<ColumnPlan> plan(nc);
+  rg.plan.resize(nc);
+  std::vector<ColumnPlan>& plan = rg.plan;
   const int grid = ctx.num_cus * 8;
   const int64_t n_blocks = std::max<int64_t>(1, (rows + PW_BLOCK_ROWS_HOST - 1) / PW_BLOCK_ROWS_HOST);
   // Several pages per chunk (round 3): pages are what a reader decodes in parallel (this library's scan: one workgroup per
@@ -248,10 +263,10 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   }
 
   // ---- the file image: PAR1, column chunks (pages: header + levels + values), footer, footer length, PAR1 -----------------
-  struct ChunkMeta { int64_t page_at, total; };
-  std::vector<ChunkMeta> meta(nc);
-  std::vector<std::vector<PagePlan>> pages(nc);
-  int64_t at = 4;
+  rg.meta.resize(nc);
+  rg.pages.resize(nc);
+  std::vector<ChunkMeta>& meta = rg.meta;
+  std::vector<std::vector<PagePlan>>& pages = rg.pages;
   for (size_t ci = 0; ci < nc; ++ci) {
     const Column& c = rec.cols[ci];
     ColumnPlan& pl = plan[ci];
@@ -305,43 +320,75 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
     meta[ci] = {at, total};
     at += total;
   }
+  // the device blocks the pages point into live as long as the plan
+  rg.keep.push_back(totals); rg.keep.push_back(d_stats);
+  for (auto& b : stats_keep) rg.keep.push_back(b);
+  return rg;
+}
+}  // namespace
+
+// One file image from one or more batches of the same schema: one row group per batch, in order (the reference writes one
+// file per record, materialize_files_task.rs:128-141; several records per file = the row-group compaction its DEV_NOTES.md
+// 117-121 asks for).
+ParquetImage records_to_parquet(Context& ctx, const std::vector<const Batch*>& ins) {
+  if (ins.empty()) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: no record batch to write"};
+  int64_t at = 4;
+  std::vector<RowGroupPlan> rgs;
+  rgs.reserve(ins.size());
+  for (const Batch* in : ins) {
+    if (!in) throw ChqError{CHQ_ERR_INVALID_HANDLE, "null record batch"};
+    rgs.push_back(plan_row_group(ctx, *in, at));
+    const RowGroupPlan& a = rgs.front(); const RowGroupPlan& b = rgs.back();
+    bool same = a.rec.cols.size() == b.rec.cols.size();
+    for (size_t ci = 0; same && ci < a.rec.cols.size(); ++ci)
+      same = a.rec.cols[ci].name == b.rec.cols[ci].name && a.plan[ci].physical == b.plan[ci].physical && a.plan[ci].string == b.plan[ci].string &&
+             a.plan[ci].optional == b.plan[ci].optional;
+    if (!same) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet: record batch " + std::to_string(rgs.size() - 1) + " has another schema than the first (names, types and nullability must agree)"};
+  }
+  const RowGroupPlan& first = rgs.front();
+  const size_t nc = first.rec.cols.size();
+  int64_t rows_all = 0;
+  for (const RowGroupPlan& rg : rgs) rows_all += rg.rows;
   ThriftOut f;
   f.i32(1, 1);
   f.list(2, ThriftOut::T_STRUCT, nc + 1);
   f.begin_element(); f.str(4, "arrow_schema"); f.i32(5, (int64_t)nc); f.end_struct();
   for (size_t ci = 0; ci < nc; ++ci) {
-    const ColumnPlan& pl = plan[ci];
+    const ColumnPlan& pl = first.plan[ci];
     f.begin_element();
-    f.i32(1, pl.physical); f.i32(3, pl.optional ? 1 : 0); f.str(4, rec.cols[ci].name);
+    f.i32(1, pl.physical); f.i32(3, pl.optional ? 1 : 0); f.str(4, first.rec.cols[ci].name);
     if (pl.string) { f.i32(6, 0); f.begin_struct(10); f.begin_struct(1); f.end_struct(); f.end_struct(); }   // UTF8 / LogicalType.STRING
     f.end_struct();
   }
-  f.i64(3, rows);
-  f.list(4, ThriftOut::T_STRUCT, 1);
-  f.begin_element();
-  f.list(1, ThriftOut::T_STRUCT, nc);
-  int64_t total_bytes = 0;
-  for (size_t ci = 0; ci < nc; ++ci) {
-    const ColumnPlan& pl = plan[ci];
+  f.i64(3, rows_all);
+  f.list(4, ThriftOut::T_STRUCT, rgs.size());
+  for (const RowGroupPlan& rg : rgs) {
     f.begin_element();
-    f.i64(2, meta[ci].page_at);
-    f.begin_struct(3);
-    f.i32(1, pl.physical);
-    f.list(2, ThriftOut::T_I32, 2); f.zigzag(PQ_PLAIN); f.zigzag(PQ_RLE);
-    f.list(3, ThriftOut::T_BINARY, 1); f.varint(rec.cols[ci].name.size()); f.o.insert(f.o.end(), rec.cols[ci].name.begin(), rec.cols[ci].name.end());
-    f.i32(4, 0); f.i64(5, rows); f.i64(6, meta[ci].total); f.i64(7, meta[ci].total); f.i64(9, meta[ci].page_at);
-    if (pl.null_count >= 0 || pl.has_minmax) {
-      f.begin_struct(12);
-      if (pl.null_count >= 0) f.i64(3, pl.null_count);
-      if (pl.has_minmax) { f.str(5, pl.max_value); f.str(6, pl.min_value); }
+    f.list(1, ThriftOut::T_STRUCT, nc);
+    int64_t total_bytes = 0;
+    for (size_t ci = 0; ci < nc; ++ci) {
+      const ColumnPlan& pl = rg.plan[ci];
+      const std::string& name = rg.rec.cols[ci].name;
+      f.begin_element();
+      f.i64(2, rg.meta[ci].page_at);
+      f.begin_struct(3);
+      f.i32(1, pl.physical);
+      f.list(2, ThriftOut::T_I32, 2); f.zigzag(PQ_PLAIN); f.zigzag(PQ_RLE);
+      f.list(3, ThriftOut::T_BINARY, 1); f.varint(name.size()); f.o.insert(f.o.end(), name.begin(), name.end());
+      f.i32(4, 0); f.i64(5, rg.rows); f.i64(6, rg.meta[ci].total); f.i64(7, rg.meta[ci].total); f.i64(9, rg.meta[ci].page_at);
+      if (pl.null_count >= 0 || pl.has_minmax) {
+        f.begin_struct(12);
+        if (pl.null_count >= 0) f.i64(3, pl.null_count);
+        if (pl.has_minmax) { f.str(5, pl.max_value); f.str(6, pl.min_value); }
+        f.end_struct();
+      }
       f.end_struct();
+      f.end_struct();
+      total_bytes += rg.meta[ci].total;
     }
+    f.i64(2, total_bytes); f.i64(3, rg.rows);
     f.end_struct();
-    f.end_struct();
-    total_bytes += meta[ci].total;
   }
-  f.i64(2, total_bytes); f.i64(3, rows);
-  f.end_struct();
   f.str(6, "chapterhouseqe_amd (MI355X page encoder)");
   // column_orders: TypeDefinedOrder for every column -- without it readers must ignore min_value / max_value
   f.list(7, ThriftOut::T_STRUCT, nc);
@@ -359,7 +406,8 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   // 62 pages per chunk, against 1.6 ms for the single-page form.
   if (at > 4) {
     size_t n_pieces = 0, blob_bytes = 0;
-    for (size_t ci = 0; ci < nc; ++ci) for (const PagePlan& pg : pages[ci]) { n_pieces += 1 + (pg.levels_dev_bytes > 0) + (pg.stream_bytes > 0); blob_bytes += pg.head.size(); }
+    for (const RowGroupPlan& rg : rgs)
+      for (size_t ci = 0; ci < nc; ++ci) for (const PagePlan& pg : rg.pages[ci]) { n_pieces += 1 + (pg.levels_dev_bytes > 0) + (pg.stream_bytes > 0); blob_bytes += pg.head.size(); }
     const size_t pieces_bytes = (n_pieces * sizeof(PwPiece) + 63) & ~(size_t)63;
     std::vector<uint8_t> up(pieces_bytes + blob_bytes);
     auto d_up = make_device_buffer(up.size() + 64, ctx.device);
@@ -367,9 +415,9 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
     PwPiece* pc = (PwPiece*)up.data();
     size_t k = 0, bo = pieces_bytes;
     unsigned long long longest = 0;
-    for (size_t ci = 0; ci < nc; ++ci) {
-      int64_t p = meta[ci].page_at;
-      for (const PagePlan& pg : pages[ci]) {
+    for (const RowGroupPlan& rg : rgs) for (size_t ci = 0; ci < nc; ++ci) {
+      int64_t p = rg.meta[ci].page_at;
+      for (const PagePlan& pg : rg.pages[ci]) {
         memcpy(up.data() + bo, pg.head.data(), pg.head.size());
         pc[k++] = PwPiece{(unsigned long long)p, (const uint8_t*)d_up->ptr + bo, (unsigned long long)pg.head.size()};
         bo += pg.head.size(); p += (int64_t)pg.head.size();
@@ -393,5 +441,7 @@ ParquetImage record_to_parquet(Context& ctx, const Batch& in) {
   check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
   return img;
 }
+
+ParquetImage record_to_parquet(Context& ctx, const Batch& in) { return records_to_parquet(ctx, std::vector<const Batch*>{&in}); }
 
 }  // namespace chq

@@ -629,6 +629,31 @@ def record_to_parquet(record: Record, *, ctx: Optional[Context] = None, copy: bo
         C.CFUNCTYPE(None, C.c_void_p)(img.release)(C.addressof(img))
 
 
+def records_to_parquet(records: Sequence[Record], *, ctx: Optional[Context] = None, copy: bool = True):
+    """Several record batches of one schema -> ONE Parquet file, one row group per batch in order
+    (`chq_records_to_parquet`): the row-group compaction the reference plans for its materialize task (DEV_NOTES.md:117-121)."""
+    if not records:
+        raise ValueError("records_to_parquet needs at least one record batch")
+    ctx = ctx or default_context()
+    prepared = [_prepare(r, ctx) for r in records]
+    arr = (C.POINTER(L.ArrowDeviceArray) * len(prepared))(*[C.pointer(p[1].array) for p in prepared])
+    img = L.ParquetImage()
+    try:
+        rc = L.lib().chq_records_to_parquet(ctx.handle, len(prepared), arr, C.byref(prepared[0][1].schema), C.byref(img))
+    finally:
+        for _c, src, own, _ in prepared:
+            if own:
+                src.release()
+    if rc:
+        raise ChqError(rc, ctx.last_error())
+    if not copy:
+        return ParquetImage(img)
+    try:
+        return C.string_at(img.data, img.len)
+    finally:
+        C.CFUNCTYPE(None, C.c_void_p)(img.release)(C.addressof(img))
+
+
 def scan_parquet(source, *, ctx: Optional[Context] = None, device_result: bool = True):
     """Every row group of a Parquet file as one batch each, decoded on the GPU (generator)."""
     f = ParquetFile(source)

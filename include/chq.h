@@ -329,9 +329,10 @@ chq_status chq_parquet_read_columns(chq_ctx* ctx, const chq_parquet* pq, int32_t
  * (operators/materialize_tasks/materialize_files_task.rs:128-141: AsyncArrowWriter::try_new(writer, schema, None),
  * write(&rec), close() -- one file with one row group per record).  `rec` (host or device resident) becomes one complete
  * Parquet file image in host memory, ready for the storage writer: the value streams of the pages are produced in HBM and
- * copied once into place, headers and footer are written on the host.  Format: PLAIN, UNCOMPRESSED, data pages V1, one
- * page per column, definition levels = the Arrow validity bitmap.  Every Parquet reader decodes it; it is not
- * byte-identical to the parquet crate's output (which dictionary-encodes and adds min/max statistics).
+ * copied once into place, headers and footer are written on the host.  Format: PLAIN, UNCOMPRESSED, data pages V1 of
+ * "parquet_page_rows" rows, definition levels = the Arrow validity bitmap, chunk statistics (null_count, min / max).  Every
+ * Parquet reader decodes it; it is not byte-identical to the parquet crate's output (which dictionary-encodes first and
+ * adds page indexes).
  * Types: Int32, Int64, Float32, Float64, Boolean, Utf8; others CHQ_ERR_NOT_SUPPORTED. */
 typedef struct chq_parquet_image {
   const uint8_t* data;   /* host memory, `len` bytes: "PAR1" ... footer ... "PAR1" */
@@ -341,6 +342,11 @@ typedef struct chq_parquet_image {
 } chq_parquet_image;
 chq_status chq_record_to_parquet(chq_ctx* ctx, const struct ArrowDeviceArray* rec, const struct ArrowSchema* schema,
                                  chq_parquet_image* out);
+/* The same for `n_records` batches of ONE schema (names, types and nullability must agree: CHQ_ERR_ARROW_INVALID_ARGUMENT
+ * otherwise): one file, one row group per batch, in order -- the compaction of several records into a larger file that the
+ * reference's DEV_NOTES.md:117-121 plans for the materialize task. */
+chq_status chq_records_to_parquet(chq_ctx* ctx, int n_records, const struct ArrowDeviceArray* const* recs,
+                                  const struct ArrowSchema* schema, chq_parquet_image* out);
 
 /* Wrap caller-owned device (or host) buffers as a record batch without copying; the buffers must
  * outlive the returned structs, whose release callbacks free only the descriptors. `format` is an

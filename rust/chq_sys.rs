@@ -221,6 +221,11 @@ extern "C" {
     pub fn chq_record_to_parquet(
         ctx: *mut chq_ctx, rec: *const ArrowDeviceArray, schema: *const FFI_ArrowSchema, out: *mut chq_parquet_image,
     ) -> c_int;
+    /// several batches of one schema -> one file, one row group per batch (the compaction DEV_NOTES.md:117-121 plans)
+    pub fn chq_records_to_parquet(
+        ctx: *mut chq_ctx, n_records: c_int, recs: *const *const ArrowDeviceArray, schema: *const FFI_ArrowSchema,
+        out: *mut chq_parquet_image,
+    ) -> c_int;
     pub fn chq_wrap_columns(
         ctx: *mut chq_ctx, cols: *const chq_column_desc, n_cols: c_int, n_rows: i64, device_type: c_int,
         out: *mut ArrowDeviceArray, out_schema: *mut FFI_ArrowSchema,

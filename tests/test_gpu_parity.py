@@ -383,6 +383,22 @@ def test_fuzz_typed_columns_vs_oracle(ctx, n):
     assert outcomes["ok"] >= 16 and outcomes["unsupported"] == 0, outcomes
 
 
+def test_typed_columns_in_sliced_batches(ctx):
+    """Arrow slices of the typed columns: Decimal128 values start at base + 16 * offset, the validity bitmaps and the Utf8
+    offsets of the boolean-word column carry the slice offset into the typed-operation kernels"""
+    rec = make_typed_batch(6000, 17)
+    for start, length in [(1, 100), (7, 2049), (63, 64), (64, 4000), (5999, 1), (13, 0)]:
+        sl = rec.slice(start, length)
+        al = empty_aliases(sl)
+        for sql in ["x1 < x2", "x1 >= x2 or w", "w and flag", "d1 <= d2 and t1 <> t2", "h < k", "h + k > f32 or u1 = u2"]:
+            assert check_same(ctx, sl, al, sql, "filter") == "ok", (sql, start, length)
+        for sql in ["x2 > x1", "w or flag", "h * k", "h + f64"]:
+            assert check_same(ctx, sl, al, sql, "value") == "ok", (sql, start, length)
+        dev = chq.DeviceRecordBatch.from_host(sl, ctx)
+        e = parse_expr("x1 < x2 and (w or h >= k)")
+        assert batches_identical(chq.filter_record(dev, al, e, ctx=ctx).to_host(), O.filter_record(sl, al, e))
+
+
 def test_typed_columns_through_projection_and_groups(ctx):
     """the same operations behind the other entry points: projection outputs of type Float16, the fused filter + projection,
     and a device-resident batch group (per-batch fallback: typed operations materialise temporaries per batch)"""

@@ -5,6 +5,7 @@ import io
 
 import numpy as np
 import pyarrow as pa
+import pyarrow.compute  # noqa: F401
 import pyarrow.parquet as pq
 import pytest
 
@@ -341,6 +342,33 @@ def test_chunks_are_cut_into_pages(ctx):
                     if expect is not None:
                         assert pages[str(i)] == (1 if one_page else expect), (fld.name, pages, expect)
     c.close()
+
+
+def test_several_records_become_one_file_with_a_row_group_each(ctx):
+    """chq_records_to_parquet: the row-group compaction the reference plans for its materialize task (DEV_NOTES.md:117-121)"""
+    from .helpers import batches_identical
+    parts = [sample_table(n, seed=50 + i, nulls=bool(i % 2), strings="mixed").to_batches()[0] for i, n in enumerate([10_000, 1, 70_000, 4096, 333])]
+    schema = parts[0].schema
+    parts = [p.cast(schema) if p.schema != schema else p for p in parts]
+    for sources in (parts, [chq.DeviceRecordBatch.from_host(p, ctx=ctx) for p in parts], [parts[0], chq.DeviceRecordBatch.from_host(parts[1], ctx=ctx)] + parts[2:]):
+        raw = chq.records_to_parquet(sources, ctx=ctx)
+        f = pq.ParquetFile(io.BytesIO(raw))
+        assert f.metadata.num_row_groups == len(parts) and f.metadata.num_rows == sum(p.num_rows for p in parts)
+        mine = chq.ParquetFile(raw)
+        for i, p in enumerate(parts):
+            assert f.metadata.row_group(i).num_rows == p.num_rows
+            assert batches_identical(f.read_row_group(i).combine_chunks().to_batches()[0], p)
+            assert batches_identical(mine.read_row_group(i, ctx=ctx).to_host(), p)
+            st = f.metadata.row_group(i).column(0).statistics
+            assert st.has_min_max and st.min == pa.compute.min(p.column(0)).as_py() and st.max == pa.compute.max(p.column(0)).as_py()
+        outs = mine.read_row_groups(ctx=ctx)
+        assert [o.num_rows for o in outs] == [p.num_rows for p in parts]
+    # one record: the same image as chq_record_to_parquet; mismatching schemas are refused
+    assert chq.records_to_parquet([parts[0]], ctx=ctx) == chq.record_to_parquet(parts[0], ctx=ctx)
+    other = pa.RecordBatch.from_arrays([pa.array([1, 2], pa.int64())], names=["id"])
+    with pytest.raises(chq.ChqError) as e:
+        chq.records_to_parquet([parts[0], other], ctx=ctx)
+    assert e.value.code == 22
 
 
 def test_sliced_batches_are_written_from_their_first_row(ctx):
