@@ -416,7 +416,14 @@ chq_status chq_filter_records(chq_ctx* ctx, int n_records, const ArrowDeviceArra
     GroupSliced sliced;
     std::vector<Batch> res = filter_records(ctx->c, gi, table_aliases, expr->e, out_device == ARROW_DEVICE_ROCM, &sliced);
     pt.mark("filter");
-    if (sliced.filled) { export_group(std::move(sliced), out_device, outs, out_schemas); pt.mark("export"); return; }
+    if (sliced.filled) {
+      std::vector<GroupSliced> more = std::move(sliced.more);
+      size_t at = sliced.ends.size();
+      export_group(std::move(sliced), out_device, outs, out_schemas);
+      for (GroupSliced& m : more) { const size_t n = m.ends.size(); export_group(std::move(m), out_device, outs + at, out_schemas + at); at += n; }
+      pt.mark("export");
+      return;
+    }
     try {
       for_each_parallel(n_records, [&](int i) { export_batch(std::move(res[(size_t)i]), out_device, &outs[i], &out_schemas[i]); });
     } catch (...) {   // no partial output

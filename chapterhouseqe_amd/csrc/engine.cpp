@@ -2096,7 +2096,8 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
       int64_t cap = 0;
       for (int64_t v : per_batch) cap += v;
       fold_cap.push_back(cap);
-      ok &= cap <= fold_rows_all * 24 && cap < (1ll << 31) - 64;   // short strings that fit ONE output column
+      // short strings that fit ONE output column (int32 offsets: 2 x group_chunk_bytes = 2 GiB unless a test lowers the option)
+      ok &= cap <= fold_rows_all * 24 && cap < 2 * ctx.opt_group_chunk_bytes - 64;
     }
     return ok;
   };
@@ -2306,7 +2307,70 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
     }
   }
   pt.mark("table");
-  if (fold && !finish_fold_sizes()) return other_path();   // (long strings / too many bytes for one column: joined on the device)
+  if (fold && !finish_fold_sizes()) {
+    // Short strings whose JOINED output would not fit int32 offsets (the reference's batch size at config-5 scale: 10^5
+    // batches, 8 GB of strings): consecutive sub-groups, each through this one-launch path -- no join on the device
+    // (2.7 ms per GiB chunk) and no Batch objects; the per-batch outputs are exported per sub-group.
+    bool short_strings = lite && !host_in && sliced && !co;
+    for (const auto& per_batch : fold_bytes) { int64_t cap = 0; for (int64_t v : per_batch) cap += v; short_strings = short_strings && cap <= fold_rows_all * 24; }
+    if (short_strings) {
+      std::vector<size_t> cuts{0};
+      {
+        std::vector<int64_t> bytes(fold_bytes.size(), 0);
+        int64_t rows = 0;
+        for (size_t b = 0; b < nb; ++b) {
+          bool over = rows + lite->rows[b] > (1ll << 30);
+          for (size_t k = 0; k < fold_bytes.size(); ++k) over |= bytes[k] + fold_bytes[k][b] > ctx.opt_group_chunk_bytes;
+          if (over && b > cuts.back()) { cuts.push_back(b); std::fill(bytes.begin(), bytes.end(), 0); rows = 0; }
+          for (size_t k = 0; k < fold_bytes.size(); ++k) bytes[k] += fold_bytes[k][b];
+          rows += lite->rows[b];
+        }
+        cuts.push_back(nb);
+      }
+      if (cuts.size() > 2) {
+        chq_call_stats acc{};
+        bool ok = true;
+        std::vector<GroupSliced> parts;
+        for (size_t k = 0; k + 1 < cuts.size() && ok; ++k) {
+          const size_t b0 = cuts[k], b1 = cuts[k + 1], n = b1 - b0;
+          GroupLite sub;
+          sub.resize(n, ncols);
+          std::copy(lite->rows.begin() + b0, lite->rows.begin() + b1, sub.rows.begin());
+          std::copy(lite->flags.begin() + b0, lite->flags.begin() + b1, sub.flags.begin());
+          std::copy(lite->values0.begin() + b0 * ncols, lite->values0.begin() + b1 * ncols, sub.values0.begin());
+          std::copy(lite->data.begin() + b0 * ncols, lite->data.begin() + b1 * ncols, sub.data.begin());
+          std::copy(lite->validity.begin() + b0 * ncols, lite->validity.begin() + b1 * ncols, sub.validity.begin());
+          std::copy(lite->offset.begin() + b0 * ncols, lite->offset.begin() + b1 * ncols, sub.offset.begin());
+          // the sub-group's first batch as a view built from the flat arrays (schema and flags of batch 0)
+          std::vector<Batch> head(1);
+          head[0] = recs[0];
+          head[0].nrows = lite->rows[b0];
+          for (size_t i = 0; i < ncols; ++i) {
+            Column& c = head[0].cols[i];
+            const size_t at = b0 * ncols + i;
+            c.owned.clear();
+            c.offset = lite->offset[at]; c.length = lite->rows[b0];
+            c.values = c.type == T_BOOL ? lite->values0[at] : lite->values0[at] - (int64_t)(c.type == T_UTF8 ? 4 : c.width) * c.offset;
+            c.data = lite->data[at]; c.data_bytes = -1;
+            c.validity = lite->validity[at]; c.null_count = c.validity ? 1 : 0;   // (unknown count: may have nulls)
+          }
+          GroupInput sgi; sgi.batches = &head; sgi.lite = &sub;
+          GroupSliced part;
+          (void)filter_records_impl(ctx, sgi, aliases, expr, out_on_device, nullptr, &part);
+          add_stats(acc, ctx.stats);
+          ok = part.filled && part.more.empty();
+          parts.push_back(std::move(part));
+        }
+        if (ok) {
+          *sliced = std::move(parts[0]);
+          for (size_t k = 1; k < parts.size(); ++k) sliced->more.push_back(std::move(parts[k]));
+          ctx.stats = acc;
+          return {};
+        }
+      }
+    }
+    return other_path();   // (long strings / too many bytes for one column: joined on the device)
+  }
   pt.mark("utf8_sizes");
   auto d_tbl = make_device_buffer(bytes_tbl + bytes_idx + bytes_cnt + 16, ctx.device);
   check_hip(hipMemcpyAsync(d_tbl->ptr, h_tbl, bytes_tbl + bytes_idx, hipMemcpyHostToDevice, ctx.stream), "upload group table");

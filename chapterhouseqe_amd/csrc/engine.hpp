@@ -219,6 +219,9 @@ struct GroupSliced {
   std::vector<Column> proto;               // per column: name / format / type / width / nullable flag
   std::vector<BufferPtr> values, data, validity;   // per column: values (Utf8: joined offsets; Boolean: joined bitmap), Utf8 bytes, joined validity bitmap or null
   std::vector<int64_t> ends;               // [nb] exclusive end row of every batch in the dense output
+  // a group too large for ONE launch (int32 offsets of the joined Utf8 output, 2^31 rows) is run as consecutive sub-groups:
+  // this struct then describes the first `ends.size()` batches and `more` the following ones, in order
+  std::vector<GroupSliced> more;
 };
 // The batches of a group call.  `batches` always holds batch 0; with `lite` the others may be missing until `materialise`
 // (imports every batch; idempotent) has run -- the one-launch path of a device-resident group works from `lite` alone, and

@@ -463,3 +463,39 @@ def test_device_groups_with_short_strings_are_filtered_straight_out_of_the_batch
                 finally:
                     ctx.set_option("tile_kind", -1)
                     ctx.set_option("group_fold", 1)
+
+
+@pytest.mark.parametrize("nulls", [False, True], ids=["non-null", "with-nulls"])
+def test_groups_too_large_for_one_launch_run_as_sub_groups(nulls):
+    """a device group of short strings whose JOINED output would not fit int32 offsets (the reference's batch size at config-5
+    scale: 10^5 batches, 8 GB of strings) runs as consecutive sub-groups, each through the one-launch path -- forced here on
+    small data with `group_chunk_bytes`: the cut positions, the per-batch outputs (device and host form) and the launch count"""
+    c = chq.Context(0)
+    rng = np.random.default_rng(77)
+    sizes = [3000] * 30 + [int(x) for x in rng.integers(2, 4000, 11)]
+    recs = []
+    for i, n in enumerate(sizes):
+        r = np.random.default_rng(900 + i)
+        v = pa.array((r.random(n) * 100).astype(np.float32), mask=(r.random(n) < 0.1) if nulls else None)
+        recs.append(pa.record_batch({"id": pa.array(r.integers(0, 1000, n).astype(np.int32)),
+                                     "value1": pa.array(["%08x" % x for x in r.integers(0, 2**32, n)]), "value2": v}))
+    al = empty_aliases(recs[0])
+    devs = [chq.DeviceRecordBatch.from_host(r, c) for r in recs]
+    for chunk_bytes, min_launches in [(1 << 30, 1), (100_000, 8), (30_000, 25)]:   # 24 kB of strings per 3000-row batch
+        c.set_option("group_chunk_bytes", chunk_bytes)
+        for sql in ["id % 2 = 0", "value2 > 50.0"]:
+            e = parse_expr(sql)
+            got = chq.filter_records(devs, al, e, ctx=c)
+            assert c.last_stats()["launches"] >= min_launches, (chunk_bytes, c.last_stats())
+            assert c.last_stats()["rows_in"] == sum(sizes)
+            host = chq.filter_records(devs, al, e, ctx=c, device_result=False)
+            for i, (g, h) in enumerate(zip(got, host)):
+                want = O.filter_record(recs[i], al, e)
+                assert batches_identical(g.to_host(), want), f"{sql}, chunk {chunk_bytes}, batch {i}:\n{explain_diff(g.to_host(), want)}"
+                assert batches_identical(h, want), (sql, chunk_bytes, i)
+            # results of different sub-groups are independent blocks: releasing some does not touch the others
+            keep = got[-1].to_host()
+            for g in got[:-1]:
+                g.release()
+            assert batches_identical(got[-1].to_host(), keep)
+    c.close()
