@@ -2327,7 +2327,9 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
         }
         cuts.push_back(nb);
       }
-      if (cuts.size() > 2) {
+      bool groups_of_two = cuts.size() > 2;   // (a sub-group of ONE batch would take the per-batch path: nothing gained -- e.g. ten 1 GB batches)
+      for (size_t k = 0; k + 1 < cuts.size(); ++k) groups_of_two = groups_of_two && cuts[k + 1] - cuts[k] >= 2;
+      if (groups_of_two) {
         chq_call_stats acc{};
         bool ok = true;
         std::vector<GroupSliced> parts;
