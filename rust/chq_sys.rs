@@ -17,6 +17,12 @@ pub struct ArrowDeviceArray {
     pub sync_event: *mut c_void,
     pub reserved: [i64; 3],
 }
+impl ArrowDeviceArray {
+    /// an array slot for the library to fill (released: `array.release` is null)
+    pub fn empty() -> ArrowDeviceArray {
+        ArrowDeviceArray { array: FFI_ArrowArray::empty(), device_id: -1, device_type: ARROW_DEVICE_CPU, sync_event: std::ptr::null_mut(), reserved: [0; 3] }
+    }
+}
 
 #[repr(C)]
 pub struct chq_ctx {

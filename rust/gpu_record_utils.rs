@@ -30,6 +30,14 @@ impl GpuContext {
         }
         Ok(GpuContext(ctx))
     }
+    /// the handle, for entry points this module does not wrap (Parquet scan / write, IPC, peer copies)
+    pub fn raw(&self) -> *mut chq_ctx {
+        self.0
+    }
+    /// chq_status -> Result, with the library's message for this context
+    pub fn check(&self, rc: i32) -> Result<()> {
+        if rc == 0 { Ok(()) } else { Err(self.err(rc)) }
+    }
     fn err(&self, rc: i32) -> anyhow::Error {
         let msg = unsafe { CStr::from_ptr(chq_ctx_last_error(self.0)) }.to_string_lossy().into_owned();
         anyhow!("[chq status {rc}] {msg}")
