@@ -45,6 +45,18 @@ class MaterializeFilesOperatorTask:
         return "materialize_files"
 
 
+@dataclasses.dataclass(frozen=True)
+class ReadFilesOperatorTask:
+    """planner::OperatorTask::TableFunc { alias, func_name: "read_files", args, max_rows_per_batch } with the path argument
+    already parsed (ReadFilesConfig::parse_config, read_files_task.rs:66-107)"""
+    path: str                       # glob below the connection's root
+    alias: Optional[str] = None
+    max_rows_per_batch: int = 10_000   # physical_planner.rs:323
+
+    def task_name(self) -> str:
+        return "read_files"
+
+
 @dataclasses.dataclass
 class OperatorInstanceConfig:
     """operator_handler_state.rs:28-35 (fields the tasks use)"""
@@ -75,6 +87,7 @@ class OperatorTaskRegistry:
         self.filter_task: Optional[TaskBuilder] = None
         self.materialize_files_task: Optional[TaskBuilder] = None
         self.materialize_data_formats: List[str] = []
+        self.table_func_tasks: dict = {}
 
     def add_filter_task_builder(self, builder: TaskBuilder) -> "OperatorTaskRegistry":
         if self.filter_task is not None:
@@ -89,7 +102,16 @@ class OperatorTaskRegistry:
         self.materialize_data_formats = list(data_formats)
         return self
 
+    def add_table_func_task_builder(self, func_name: str, builder: TaskBuilder) -> "OperatorTaskRegistry":
+        """operator_task_registry.rs:35-49 (the syntax validator is the planner's business: out of scope)"""
+        if func_name in self.table_func_tasks:
+            raise OperatorTaskRegistryError(f"table func task builder for {func_name} already set")
+        self.table_func_tasks[func_name] = builder
+        return self
+
     def find_task_builder(self, task) -> Optional[TaskBuilder]:
+        if isinstance(task, ReadFilesOperatorTask):
+            return self.table_func_tasks.get("read_files")
         if isinstance(task, FilterOperatorTask):
             return self.filter_task
         if isinstance(task, MaterializeFilesOperatorTask):
@@ -204,6 +226,110 @@ class FilterTaskBuilder(TaskBuilder):
         return run
 
 
+# ---- read_files (the table function in front of the path) -----------------------------------------------------
+class ReadFilesTask:
+    """read_files_task.rs:129-291 with `read_records` (:233-282) on the GPU: every matching Parquet file is opened through a
+    RANGE reader (the footer, then exactly the chunks that are decoded -- the reference reads through opendal ranges), its row
+    groups are decoded in HBM (`chq_parquet_read_columns`) and forwarded as device-resident records cut into zero-copy slices
+    of `max_rows_per_batch` rows; `columns` prunes the scan (the reference's DEV_NOTES.md:123).  Files the decoder refuses
+    (status 30: ZSTD, nested columns, ...) are read with pyarrow on the host -- the stand-in for the parquet crate."""
+
+    def __init__(self, op_in_config: OperatorInstanceConfig, task: ReadFilesOperatorTask, storage_root: str, outbound_exchange,
+                 ctx=None, columns: Optional[Sequence[str]] = None, device_records: bool = True):
+        self.operator_instance_config = op_in_config
+        self.config = task
+        self.storage_root = storage_root
+        self.outbound_exchange = outbound_exchange
+        self._ctx = ctx
+        self.columns = list(columns) if columns is not None else None
+        self.device_records = device_records
+        self.record_id = 0
+        self.files_read: List[str] = []
+        self.bytes_fetched = 0
+        self.host_fallbacks = 0
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = record_utils.Context(self.operator_instance_config.device_id)
+        return self._ctx
+
+    def _send(self, rec_handler, record) -> None:
+        aliases = record_utils.get_record_table_aliases(self.config.alias, record)
+        rec_handler.send_record_to_outbound_exchange(self.record_id, record, aliases)
+        self.record_id += 1
+
+    def _read_records(self, rec_handler, path: str) -> None:
+        size = os.path.getsize(path)
+        step = max(1, int(self.config.max_rows_per_batch))
+        with open(path, "rb") as fh:
+            def read(offset: int, length: int) -> bytes:
+                self.bytes_fetched += length
+                return os.pread(fh.fileno(), length, offset)
+            try:
+                pf = record_utils.ParquetFile(None, reader=read, size=size)
+            except record_utils.ChqError as err:
+                if err.code != 30:
+                    raise
+                pf = None
+            groups = None
+            if pf is not None:
+                try:
+                    groups = pf.read_row_groups(ctx=self._context(), device_result=self.device_records, columns=self.columns)
+                except record_utils.ChqError as err:
+                    if err.code != 30:
+                        raise
+                finally:
+                    pf.close()
+        if groups is None:   # outside the GPU decoder's scope: the host reader, same batch size
+            import pyarrow.parquet as pq
+            self.host_fallbacks += 1
+            for rec in pq.ParquetFile(path).iter_batches(batch_size=step, columns=self.columns):
+                self._send(rec_handler, rec)
+            return
+        for group in groups:
+            n = group.num_rows
+            if n <= step:
+                self._send(rec_handler, group)
+                continue
+            for at in range(0, n, step):
+                self._send(rec_handler, group.slice(at, min(step, n - at)))
+
+    def async_main(self) -> None:
+        import glob
+        rec_handler = RecordHandler.initiate(self.operator_instance_config, [], self.outbound_exchange)
+        try:
+            for path in sorted(glob.glob(os.path.join(self.storage_root, self.config.path.lstrip("/")), recursive=True)):
+                self._read_records(rec_handler, path)
+                self.files_read.append(path)
+        finally:
+            rec_handler.close()
+
+
+class ReadFilesTaskBuilder(TaskBuilder):
+    """The GPU read_files table function (`rust/gpu_read_files_task.rs` is the same task for the reference's registry)."""
+
+    def __init__(self, storage_root: str, columns: Optional[Sequence[str]] = None, device_records: bool = True):
+        self._root = storage_root
+        self._columns = columns
+        self._device_records = device_records
+
+    def build(self, op_in_config, inbound_exchanges, outbound_exchange):
+        if not isinstance(op_in_config.task, ReadFilesOperatorTask):
+            raise ValueError("operator instance config is not a read_files task")
+        task = ReadFilesTask(op_in_config, op_in_config.task, self._root, outbound_exchange, columns=self._columns,
+                             device_records=self._device_records)
+
+        def run():
+            try:
+                task.async_main()
+                return None
+            except Exception as err:   # noqa: BLE001
+                return err
+
+        run.task = task
+        return run
+
+
 # ---- materialize ----------------------------------------------------------------------------------------------
 @dataclasses.dataclass(frozen=True)
 class MaterializeFilesConfig:
@@ -302,5 +428,6 @@ class MaterializeFilesTaskBuilder(TaskBuilder):
 def build_default_operator_task_registry(storage_root: str) -> OperatorTaskRegistry:
     """operator_task_registry.rs:150-162 with the GPU builders swapped in."""
     return (OperatorTaskRegistry()
+            .add_table_func_task_builder("read_files", ReadFilesTaskBuilder(storage_root))
             .add_filter_task_builder(FilterTaskBuilder())
             .add_materialize_files_builder(MaterializeFilesTaskBuilder(storage_root), ["parquet"]))

@@ -169,6 +169,19 @@ class DeviceRecordBatch:
                         "data": bufs[2] if len(bufs) > 2 else 0})
         return out
 
+    def slice(self, offset: int, length: Optional[int] = None) -> "DeviceRecordBatch":
+        """Rows [offset, offset + length) as a zero-copy view (Arrow slice: the same buffers, a larger element offset); the
+        view keeps this batch alive.  Null counts of nullable columns become unknown (-1), as for any Arrow slice."""
+        n = self.num_rows
+        offset = max(0, min(int(offset), n))
+        length = n - offset if length is None else max(0, min(int(length), n - offset))
+        cols = self.describe_columns()
+        for c in cols:
+            c["offset"] += offset
+            if c["validity"] and c["null_count"] != 0:
+                c["null_count"] = -1
+        return DeviceRecordBatch.from_device_buffers(cols, length, ctx=self.ctx, keepalive=[self])
+
     @staticmethod
     def from_device_buffers(columns: Sequence[dict], num_rows: int, ctx: Optional[Context] = None,
                             keepalive=None) -> "DeviceRecordBatch":

@@ -219,3 +219,97 @@ def test_steady_state_calls_do_not_grow_memory():
     assert free0 - free1 < 64 << 20, f"HBM in use grew by {(free0 - free1) >> 20} MiB over 300 rounds"
     assert rss1 - rss0 < 256 << 10, f"peak RSS grew by {(rss1 - rss0) >> 10} MiB over 300 rounds"      # ru_maxrss is in KiB
     ctx.close()
+
+
+@pytest.mark.parametrize("compression", ["NONE", "SNAPPY"])
+def test_read_files_filter_materialize_dag_on_the_device(tmp_path, compression):
+    """The reference's whole DAG for `select ... from read_files('data/*.parquet') where ...` (README.md:88-92) through the
+    operator mirrors: [read_files] -> exchange -> [filter] -> exchange -> [materialize], every operator on the GPU -- the scan
+    decodes row groups in HBM (range reads, only the columns the query uses), records travel as zero-copy device slices of
+    max_rows_per_batch rows, the result files are encoded from HBM.  Checked per record id against the oracle."""
+    import threading
+
+    import numpy as np
+    import pyarrow as pa
+
+    from chapterhouseqe_amd.operators.exchange_operator import ExchangeOperator
+    from chapterhouseqe_amd.operators.tasks import (FilterOperatorTask, FilterTaskBuilder, MaterializeFilesOperatorTask, MaterializeFilesTaskBuilder,
+                                                     OperatorInstanceConfig, OperatorTaskRegistry, ReadFilesOperatorTask, ReadFilesTaskBuilder)
+    rng = np.random.default_rng(8)
+    root = tmp_path / "storage"
+    (root / "data").mkdir(parents=True)
+    tables = []
+    for k, n in enumerate([25_000, 7, 12_345]):
+        t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32) + 100_000 * k),
+                      "value1": pa.array(["%08x" % v for v in rng.integers(0, 2**32, n)]),
+                      "value2": pa.array((rng.random(n) * 100).astype(np.float32), mask=rng.random(n) < 0.05),
+                      "unused": pa.array(rng.integers(0, 2**62, n).astype(np.int64)), "unused2": pa.array(rng.random(n))})
+        pq.write_table(t, root / "data" / f"part{k}.parquet", compression=compression, row_group_size=10_000)
+        tables.append(t)
+    (root / "data" / "notes.txt").write_text("not a parquet file")
+    sql = "select id, value1, value2 * 2.0 as twice from read_files('data/*.parquet') where value2 > 10.0"
+    sel = parse_select(sql)
+    ex0 = ExchangeOperator("operator_p0_exchange", ["operator_p1_producer"])
+    ex1 = ExchangeOperator("operator_p1_exchange", ["operator_p2_producer"])
+    out_root = tmp_path / "results"
+    reg = (OperatorTaskRegistry()
+           .add_table_func_task_builder("read_files", ReadFilesTaskBuilder(str(root), columns=["id", "value1", "value2"]))
+           .add_filter_task_builder(FilterTaskBuilder(group_size=16))
+           .add_materialize_files_builder(MaterializeFilesTaskBuilder(str(out_root)), ["parquet"]))
+    rtask = ReadFilesOperatorTask("data/*.parquet", alias=None, max_rows_per_batch=4_000)
+    rrun = reg.find_task_builder(rtask).build(OperatorInstanceConfig(1, "operator_p0_producer", 7, rtask), [], ex0)
+    assert rrun() is None
+    ex0.producers_completed()
+    reader = rrun.task
+    assert len(reader.files_read) == 3 and reader.host_fallbacks == 0
+    sizes = sum(os.path.getsize(root / "data" / f"part{k}.parquet") for k in range(3))
+    assert reader.bytes_fetched < sizes          # the `unused` column's chunks were never read
+    # records: every 10 000-row row group in slices of at most 4 000 rows, in file order
+    want_records = []
+    for t in tables:
+        for g in range(0, t.num_rows, 10_000):
+            grp = t.slice(g, min(10_000, t.num_rows - g)).select(["id", "value1", "value2"])
+            for at in range(0, grp.num_rows, 4_000):
+                want_records.append(grp.slice(at, min(4_000, grp.num_rows - at)).combine_chunks().to_batches()[0])
+    assert reader.record_id == len(want_records)
+    ftask = FilterOperatorTask(sel.selection)
+    frun = reg.find_task_builder(ftask).build(OperatorInstanceConfig(2, "operator_p1_producer", 7, ftask), [ex0], ex1)
+    err = [None]
+    th = threading.Thread(target=lambda: err.__setitem__(0, frun()))
+    th.start(); th.join()
+    assert err[0] is None and frun.task.records_processed == len(want_records) and frun.task.group_calls >= 1
+    ex1.producers_completed()
+    mtask = MaterializeFilesOperatorTask("parquet", sel.projection)
+    mrun = reg.find_task_builder(mtask).build(OperatorInstanceConfig(3, "operator_p2_producer", 7, mtask), [ex1], None)
+    assert mrun() is None
+    d = os.path.dirname(mrun.task.files_written[0])
+    for rid, rec in enumerate(want_records):
+        al = [[] for _ in range(rec.num_columns)]
+        exp = O.project_record(sel.projection, O.filter_record(rec, al, sel.selection), al)
+        got = pq.read_table(os.path.join(d, f"rec_{rid}.parquet")).to_batches()
+        got = got[0] if got else exp.slice(0, 0)
+        assert got.to_pydict() == exp.to_pydict(), rid
+
+
+def test_device_batch_slices_are_views():
+    import numpy as np
+    import pyarrow as pa
+    from .helpers import batches_identical
+    c = chq.Context(0)
+    rng = np.random.default_rng(3)
+    n = 5000
+    rec = pa.RecordBatch.from_arrays([pa.array(np.arange(n, dtype=np.int32)), pa.array(["s%d" % i for i in range(n)]),
+                                      pa.array(rng.random(n), mask=rng.random(n) < 0.2), pa.array(rng.integers(0, 2, n).astype(bool))],
+                                     names=["id", "s", "x", "b"])
+    dev = chq.DeviceRecordBatch.from_host(rec, c)
+    for off, ln in [(0, n), (1, 100), (63, 65), (4999, 1), (17, 0), (4000, None)]:
+        sl = dev.slice(off, ln)
+        want = rec.slice(off, ln) if ln is not None else rec.slice(off)
+        assert batches_identical(sl.to_host(), want), (off, ln)
+        e = parse_select("select * from t where x > 0.5 and id % 3 = 0").selection
+        al = [[] for _ in range(4)]
+        assert batches_identical(chq.filter_record(sl, al, e, ctx=c).to_host(), O.filter_record(want, al, e)), (off, ln)
+    sl = dev.slice(10, 20)
+    del dev   # the view keeps the parent's buffers alive
+    assert sl.to_host().column(0).to_pylist() == list(range(10, 30))
+    c.close()
