@@ -361,7 +361,11 @@ def main():
              "group_call_ms": per_call[len(per_call) // 2], "c_call_ms": min(ccall), "us_per_batch_c_call": min(ccall) * 1e3 / nb,
              "coalesced_call_ms": coalesced_ms, "per_batch_loop_us_per_batch": loop_us,
              "us_per_batch_group_call": per_call[len(per_call) // 2] * 1e3 / nb, "alg_bytes": alg,
-             "group_call_GBps": alg / (per_call[len(per_call) // 2] * 1e-3) / 1e9, "note": note}
+             "group_call_GBps": alg / (per_call[len(per_call) // 2] * 1e-3) / 1e9,
+             "c_call_GBps": alg / (min(ccall) * 1e-3) / 1e9,
+             "fields": "c_call_ms = chq_filter_records through ctypes (one Arrow struct per output batch: the product); group_call_ms = the "
+                       "Python mirror chq.filter_records, which also builds one Python object per output batch (~2.6 us each)",
+             "note": note}
         results.append(r)
         print(json.dumps(r), flush=True)
         grp.release()
