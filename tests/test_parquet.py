@@ -163,3 +163,35 @@ def test_sizes_near_int64_max_are_compared_by_subtraction():
         rc = L.lib().chq_parquet_open(patched, len(patched), C.byref(f), err, len(err))
         assert rc == 22, (rc, err.value)
         assert not f.value
+
+
+def test_damaged_metadata_across_codecs_and_page_versions_never_crashes():
+    """Mutation fuzz of the metadata reader (footer + page headers, the hand-written Thrift reader): random byte changes in
+    valid files (uncompressed V1, snappy V2, small PLAIN pages) must end in a parsed description or in a ChqError, never in
+    a crash or a hang -- read_files takes user files (sizes and counts of an untrusted file)."""
+    rng = np.random.default_rng(9)
+    n = 3000
+    t = pa.table({"id": pa.array(np.arange(n, dtype=np.int32)), "s": pa.array(["v%d" % (i % 50) for i in range(n)]),
+                  "x": pa.array(rng.random(n).astype(np.float32), mask=rng.random(n) < 0.1)})
+    raws = []
+    for kw in (dict(compression="NONE"), dict(compression="SNAPPY", data_page_version="2.0"),
+               dict(compression="NONE", use_dictionary=False, data_page_size=2048)):
+        b = io.BytesIO()
+        pq.write_table(t, b, row_group_size=1000, **kw)
+        raws.append(b.getvalue())
+    parsed = rejected = 0
+    for it in range(900):
+        raw = bytearray(raws[it % len(raws)])
+        footer_at = len(raw) - 8 - int.from_bytes(raw[-8:-4], "little")
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(footer_at, len(raw))) if rng.random() < 0.7 else int(rng.integers(4, footer_at))
+            mode = rng.random()
+            raw[pos] = int(rng.integers(0, 256)) if mode < 0.5 else (raw[pos] ^ (1 << int(rng.integers(0, 8)))) if mode < 0.8 else 0xFF
+        try:
+            f = chq.ParquetFile(bytes(raw))
+            f.describe()
+            f.close()
+            parsed += 1
+        except chq.ChqError:
+            rejected += 1
+    assert parsed + rejected == 900 and rejected > 100 and parsed > 100, (parsed, rejected)
