@@ -176,6 +176,40 @@ def test_every_pair_of_types_and_literals():
     assert counts["ok"] > 400 and counts["error"] > 400, counts
 
 
+def test_every_pair_of_the_round_3_types():
+    """Float16, temporal and decimal columns against each other, against the numeric / Boolean / Utf8 columns and against
+    literals, under every operator: the host planner answers what the oracle answers (status and result type) -- the
+    `left == right` arm and the Float16 rows of get_common_type (compute_value.rs:355, :387-390), arrow-arith's refusals for
+    dates / times, arrow-cast's refusals under AND / OR"""
+    import decimal
+    n = 4
+    ints32, ints64 = pa.array(np.arange(1, n + 1), pa.int32()), pa.array(np.arange(1, n + 1), pa.int64())
+    cols = {
+        "h": pa.array(np.arange(1, n + 1).astype(np.float16), pa.float16()), "h2": pa.array(np.arange(2, n + 2).astype(np.float16), pa.float16()),
+        "d32": ints32.view(pa.date32()), "d32b": ints32.view(pa.date32()), "d64": ints64.view(pa.date64()),
+        "ts": ints64.view(pa.timestamp("s")), "ts2": ints64.view(pa.timestamp("s")), "tms": ints64.view(pa.timestamp("ms")),
+        "tz": ints64.view(pa.timestamp("s", tz="UTC")), "t32": ints32.view(pa.time32("s")), "t64": ints64.view(pa.time64("us")),
+        "du": ints64.view(pa.duration("ms")), "du2": ints64.view(pa.duration("ms")),
+        "dec": pa.array([decimal.Decimal(i) for i in range(1, n + 1)], pa.decimal128(20, 2)),
+        "dec2": pa.array([decimal.Decimal(i) for i in range(2, n + 2)], pa.decimal128(20, 2)),
+        "dec3": pa.array([decimal.Decimal(i) for i in range(1, n + 1)], pa.decimal128(20, 3)),
+        "i32": ints32, "i64": ints64, "f32": pa.array(np.arange(1, n + 1).astype(np.float32)), "f64": pa.array(np.arange(1, n + 1).astype(np.float64)),
+        "flag": pa.array([True, False, True, True]), "s": pa.array(["true", "no", "x", "1"]),
+    }
+    rec = pa.RecordBatch.from_arrays(list(cols.values()), names=list(cols))
+    al = empty_aliases(rec)
+    new = ["h", "h2", "d32", "d32b", "d64", "ts", "ts2", "tms", "tz", "t32", "t64", "du", "du2", "dec", "dec2", "dec3"]
+    others = ["i32", "i64", "f32", "f64", "flag", "s", "3", "2.5", "'x'", "true"]
+    counts = {}
+    for a in new:
+        for b in new + others:
+            for op in ["+", "*", "/", "%", "<", "=", "<>", ">=", "and", "or"]:
+                for sql in (f"{a} {op} {b}", f"{b} {op} {a}"):
+                    r = check(rec, al, sql)
+                    counts[r] = counts.get(r, 0) + 1
+    assert counts["ok"] > 150 and counts["error"] > 2000 and counts.get("unsupported", 0) > 10, counts
+
+
 def test_random_expressions_type_the_same_way():
     from .test_gpu_parity import random_numeric, random_predicate
     rng = np.random.default_rng(5)
