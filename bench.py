@@ -507,7 +507,8 @@ def config5_main(args, chq, torch, dist, rank, local_rank, world, dev, ctx, comm
                        "validated_vs_oracle_rows": args.validate_rows if validated else 0, "per_gpu_rows_per_s": per_gpu},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
-                         "kernel": "filter_fused_kernel<1024,16,...,NU=2> (Utf8 column filtered in the same pass), one launch (+ tail) per batch",
+                         "kernel": "per batch: utf8_uniform_kernel (proves the strings all have 8 bytes) + filter_fused_kernel<1024,16,FULL> (+ tail) "
+                                   "with the string column copied as a fixed-width column + iota_offsets_kernel; all three are timed",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_per_gpu,
                          "aggregate_GBps": (achieved * world) if achieved else None,
                          "frac_of_n_x_peak": (achieved / HBM_PEAK_GBPS) if achieved else None},

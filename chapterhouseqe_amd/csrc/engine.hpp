@@ -13,6 +13,7 @@
 
 #include "../../include/chq.h"
 #include "device_program.h"
+#include "typed_ops.h"
 #include "plan.hpp"
 
 namespace chq {
@@ -25,6 +26,9 @@ hipError_t launch_bit_compact(const BitCompactParams& p, int grid, hipStream_t s
 hipError_t launch_bit_compact_group(const BitCompactGroupParams& p, int grid, hipStream_t stream);
 hipError_t launch_cmp128(const Cmp128Params& p, hipStream_t stream);
 hipError_t launch_utf8_to_bool(const Utf8ToBoolParams& p, hipStream_t stream);
+hipError_t launch_utf8_uniform(const Utf8UniformParams& p, hipStream_t stream);
+hipError_t launch_iota_offsets(const IotaOffsetsParams& p, hipStream_t stream);
+hipError_t launch_utf8_uniform_group(const Utf8UniformGroupParams& p, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);
@@ -127,6 +131,7 @@ struct Context {
   int64_t opt_large_host_rows = 8 << 20;
   int64_t opt_large_host_chunk = 0;  // rows per chunk (0: about 64 MB of input)
   int64_t opt_group_bits = 1;       // wave-packed device groups with validity bitmaps / Boolean columns take the one-launch path (0: joined first)
+  int64_t opt_uniform_utf8_rows = 1 << 24;   // batches from this size on (below it the extra pass and its read-back cost more than the copy saves): Utf8 columns whose values all have one length are filtered as fixed-width columns (0: never)
   int64_t opt_parquet_page_rows = 65536;   // chq_record_to_parquet: rows per data page (multiples of 4096; at most 64 pages per chunk)
   int64_t opt_group_fold = 1;       // device-resident groups with short-string Utf8 columns: filtered straight out of the batches (0: joined first)
   int64_t opt_fold_utf8 = 1;        // short-string Utf8 columns are filtered inside filter_fused_kernel (0: always the separate Utf8 pass)

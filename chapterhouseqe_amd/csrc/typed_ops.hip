@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_program.h"
+#include "typed_ops.h"
 
 namespace chq {
 namespace {
@@ -115,12 +116,55 @@ __global__ __launch_bounds__(256) void utf8_to_bool_kernel(const Utf8ToBoolParam
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void utf8_uniform_kernel(const Utf8UniformParams p) {
+  const int32_t first = p.offsets[0], len = p.offsets[1] - first;
+  bool differs = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.nrows; i += (int64_t)gridDim.x * 256)
+    differs |= p.offsets[i + 1] - p.offsets[i] != len;   // (every offset is read twice, by neighbouring lanes: one line)
+  if (__ballot(differs) != 0 && (threadIdx.x & 63) == 0) atomicOr((unsigned*)&p.out[0], 1u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { p.out[1] = len; p.out[2] = first; }
+}
+__global__ __launch_bounds__(256) void utf8_uniform_group_kernel(const Utf8UniformGroupParams p) {
+  __shared__ int s_differs;
+  for (int64_t b = blockIdx.x; b < p.nb; b += gridDim.x) {
+    const int32_t* offs = (const int32_t*)(uintptr_t)p.offsets_of[b];
+    const int64_t rows = p.rows_of[b];
+    if (threadIdx.x == 0) s_differs = 0;
+    __syncthreads();
+    const int32_t first = offs[0], len = rows > 0 ? offs[1] - first : 0;
+    bool differs = false;
+    for (int64_t i = threadIdx.x; i < rows; i += 256) differs |= offs[i + 1] - offs[i] != len;
+    if (differs) s_differs = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) { p.out[3 * b] = s_differs; p.out[3 * b + 1] = len; p.out[3 * b + 2] = first; }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void iota_offsets_kernel(const IotaOffsetsParams p) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n_plus_1; i += (int64_t)gridDim.x * 256) p.out[i] = (int32_t)(i * p.step);
+}
+}  // namespace
+
 static int grid_for(int64_t nrows) {
   const int64_t blocks = (nrows + 255) / 256;
   return (int)(blocks < 1 ? 1 : blocks > 256 * 32 ? 256 * 32 : blocks);
 }
 hipError_t launch_cmp128(const Cmp128Params& p, hipStream_t stream) {
   hipLaunchKernelGGL(cmp128_kernel, dim3(grid_for(p.nrows)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_utf8_uniform(const Utf8UniformParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(utf8_uniform_kernel, dim3(grid_for(p.nrows)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_utf8_uniform_group(const Utf8UniformGroupParams& p, hipStream_t stream) {
+  if (p.nb <= 0) return hipSuccess;
+  hipLaunchKernelGGL(utf8_uniform_group_kernel, dim3((unsigned)(p.nb < 65535 * 16 ? p.nb : 65535 * 16)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_iota_offsets(const IotaOffsetsParams& p, hipStream_t stream) {
+  hipLaunchKernelGGL(iota_offsets_kernel, dim3(grid_for(p.n_plus_1)), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 hipError_t launch_utf8_to_bool(const Utf8ToBoolParams& p, hipStream_t stream) {

@@ -93,7 +93,8 @@ void* chq_ctx_stream(const chq_ctx* ctx);
  * measurements and tests (all default 1): "fold_utf8" (short-string Utf8 columns inside the main kernel), "group_fold"
  * (the same for batch groups), "group_bits" (validity bitmaps / Boolean columns of a wave-packed device group in the
  * one-launch path), "stash" (-1 auto .. 2 predicate columns kept in LDS between the two phases), "split_rows" (rows from
- * which a batch is launched as complete tiles + tail), "parquet_page_rows" (chq_record_to_parquet: rows per data page,
+ * which a batch is launched as complete tiles + tail), "uniform_utf8_rows" (batches of at least this many rows -- default 2^24, 0 = never -- have
+ * their Utf8 columns checked for ONE value length and, if so, filtered as fixed-width columns), "parquet_page_rows" (chq_record_to_parquet: rows per data page,
  * default 65 536, rounded to multiples of 4 096; a chunk never gets more than 64 pages).  Unknown keys fail.
  *
  * Type coverage of expressions = the reference's (RU/compute_value.rs:350-431): the integer / float coercion table,

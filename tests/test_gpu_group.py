@@ -499,3 +499,44 @@ def test_groups_too_large_for_one_launch_run_as_sub_groups(nulls):
                 g.release()
             assert batches_identical(got[-1].to_host(), keep)
     c.close()
+
+
+@pytest.mark.parametrize("nulls", [False, True], ids=["non-null", "value2-with-nulls"])
+def test_groups_of_uniform_length_strings_run_as_plain_groups(nulls):
+    """device groups whose string columns all hold values of ONE length (the reference's sample strings) are proved uniform by
+    one pass over the offsets and filtered as fixed-width columns: per-batch outputs, the joined form and the host form
+    against the oracle, next to groups that must keep the string path (one ragged value; a 3-byte length)"""
+    c = chq.Context(0)
+    c.set_option("uniform_utf8_rows", 1000)   # (default: groups of 2^24 rows and more)
+    rng = np.random.default_rng(5)
+    sizes = [3000] * 20 + [int(x) for x in rng.integers(2, 4000, 9)]
+
+    def group(fmt, spoil=None):
+        recs = []
+        for i, n in enumerate(sizes):
+            r = np.random.default_rng(700 + i)
+            s = [fmt % x for x in r.integers(0, 2**24, n)]
+            if spoil is not None and i == spoil:
+                s[n // 2] = "x"
+            v = pa.array((r.random(n) * 100).astype(np.float32), mask=(r.random(n) < 0.1) if nulls else None)
+            recs.append(pa.record_batch({"id": pa.array(r.integers(0, 1000, n).astype(np.int32)), "value1": pa.array(s), "value2": v,
+                                         "key16": pa.array(["%016x" % x for x in r.integers(0, 2**62, n)])}))
+        return recs
+
+    for recs in (group("%08x"), group("%08x", spoil=17), group("%03x")):
+        al = empty_aliases(recs[0])
+        devs = [chq.DeviceRecordBatch.from_host(r, c) for r in recs]
+        for sql in ["id % 2 = 0", "value2 > 50.0", "id < 0"]:
+            e = parse_expr(sql)
+            want = [O.filter_record(r, al, e) for r in recs]
+            got = chq.filter_records(devs, al, e, ctx=c)
+            host = chq.filter_records(devs, al, e, ctx=c, device_result=False)
+            for i in range(len(recs)):
+                assert batches_identical(got[i].to_host(), want[i]), f"{sql}, batch {i}:\n{explain_diff(got[i].to_host(), want[i])}"
+                assert batches_identical(host[i], want[i]), (sql, i)
+            big, per = chq.filter_records_coalesced(devs, al, e, ctx=c)
+            assert per == [w.num_rows for w in want]
+            whole = pa.Table.from_batches(want).combine_chunks().to_batches()
+            if big.num_rows:
+                assert batches_identical(big.to_host(), whole[0], check_nullable=False), sql
+    c.close()

@@ -147,3 +147,43 @@ def test_device_resident_column_of_unknown_span(ctx):
     assert np.array_equal(got, exp)
     assert np.array_equal(host.column(0).to_numpy(), np.arange(0, n, 2, dtype=np.int32))
     c.close()
+
+
+def test_uniform_length_strings_take_the_fixed_width_copy():
+    """Utf8 columns whose values all have one length (1, 2, 4, 8 or 16 bytes) are filtered as fixed-width columns once a pass
+    over the offsets has proved it; anything else -- one ragged value, an unsupported length, nulls, a predicate that reads
+    the column -- keeps the ordinary string paths.  Same answers either way (oracle), slices included."""
+    import numpy as np
+    import pyarrow as pa
+    from chapterhouseqe_amd.sqlparse import parse_expr
+    from oracle import oracle as O
+    from .helpers import batches_identical, explain_diff
+    c = chq.Context(0)
+    c.set_option("uniform_utf8_rows", 1000)    # (default: batches of 2^24 rows and more)
+    rng = np.random.default_rng(31)
+    n = 70_001
+
+    def fixed(width, seed):
+        r = np.random.default_rng(seed)
+        return pa.array(["".join(chr(97 + int(x)) for x in row) for row in r.integers(0, 26, (n, width))], pa.utf8())
+
+    ragged = pa.array(["r" * int(l) for l in rng.integers(0, 12, n)], pa.utf8())
+    almost = fixed(8, 5).to_pylist(); almost[n - 7] = "short"
+    with_nulls = pa.array(fixed(8, 6).to_pylist(), pa.utf8(), mask=rng.random(n) < 0.1)
+    rec = pa.RecordBatch.from_arrays(
+        [pa.array(np.arange(n, dtype=np.int32)), fixed(8, 1), fixed(16, 2), fixed(1, 3), fixed(3, 4), ragged, pa.array(almost, pa.utf8()), with_nulls,
+         pa.array((rng.random(n) * 100).astype(np.float32)), pa.array(["é%06d" % i for i in range(n)], pa.utf8())],   # 8 BYTES each: 2 + 6
+        names=["id", "k8", "k16", "k1", "k3", "rag", "almost", "nul", "v", "utf8bytes"])
+    al = [[] for _ in range(rec.num_columns)]
+    for sl in (rec, rec.slice(13, 50_000), rec.slice(69_000)):
+        dev = chq.DeviceRecordBatch.from_host(sl, c)
+        for sql in ["id % 2 = 0", "v > 10.0", "v > 99.5", "id < 0", "k8 >= 'n' and v < 50.0", "k16 < 'c'"]:
+            e = parse_expr(sql)
+            want = O.filter_record(sl, al, e)
+            got = chq.filter_record(dev, al, e, ctx=c).to_host()
+            assert batches_identical(got, want), f"{sql} ({sl.num_rows} rows):\n{explain_diff(got, want)}"
+            c.set_option("uniform_utf8_rows", 0)
+            ref = chq.filter_record(dev, al, e, ctx=c).to_host()
+            c.set_option("uniform_utf8_rows", 1000)
+            assert batches_identical(got, ref), sql
+    c.close()
