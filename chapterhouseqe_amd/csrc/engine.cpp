@@ -2165,7 +2165,10 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
     if (foldable) sizes_in_flight = device_utf8_bytes_issue(ctx, recs, lite, fold_utf8);
   }
   bool fold = !plain && foldable;
+  bool sizes_done = false, sizes_ok = false;
   auto finish_fold_sizes = [&]() -> bool {   // false: long strings, or more than one output column can address
+    if (sizes_done) return sizes_ok;
+    sizes_done = true;
     fold_bytes = device_utf8_bytes_finish(ctx, sizes_in_flight);
     bool ok = true;
     for (const auto& per_batch : fold_bytes) {
@@ -2175,6 +2178,7 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
       // short strings that fit ONE output column (int32 offsets: 2 x group_chunk_bytes = 2 GiB unless a test lowers the option)
       ok &= cap <= fold_rows_all * 24 && cap < 2 * ctx.opt_group_chunk_bytes - 64;
     }
+    sizes_ok = ok;
     return ok;
   };
   pt.mark("eligibility+utf8_sizes");
@@ -2247,8 +2251,8 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
   if (fold && lite && !host_in && (sliced || co) && ctx.opt_uniform_utf8_rows > 0 && total_rows >= ctx.opt_uniform_utf8_rows) {
     bool pred_reads_utf8 = false;
     for (int r : lw.refs) pred_reads_utf8 |= recs[0].cols[(size_t)r].type == T_UTF8;
-    if (!pred_reads_utf8) {
-      if (!sizes_in_flight.cols.empty()) check_hip(hipStreamSynchronize(ctx.stream), "hipStreamSynchronize");
+    // (a group whose joined strings do not fit ONE output column is cut into sub-groups first: each comes back here)
+    if (!pred_reads_utf8 && finish_fold_sizes()) {
       const size_t nu = fold_utf8.size();
       std::vector<unsigned long long> h_in((nu + 1) * nb);
       for (size_t b = 0; b < nb; ++b) h_in[b] = (unsigned long long)lite->rows[b];
@@ -2257,9 +2261,10 @@ std::vector<Batch> filter_records_impl(Context& ctx, const GroupInput& gi, const
       auto d_in = make_device_buffer(h_in.size() * 8 + 16, ctx.device);
       auto d_out = make_device_buffer(nu * nb * 12 + 16, ctx.device);
       check_hip(hipMemcpyAsync(d_in->ptr, h_in.data(), h_in.size() * 8, hipMemcpyHostToDevice, ctx.stream), "upload offsets table");
+      check_hip(hipMemsetAsync(d_out->ptr, 0, nu * nb * 12, ctx.stream), "memset");
       for (size_t k = 0; k < nu; ++k) {
         Utf8UniformGroupParams up{(const unsigned long long*)d_in->ptr + (k + 1) * nb, (const long long*)d_in->ptr, (int64_t)nb, (int32_t*)d_out->ptr + 3 * k * nb};
-        check_hip(launch_utf8_uniform_group(up, ctx.stream), "launch utf8_uniform_group_kernel");
+        check_hip(launch_utf8_uniform_group(up, max_rows, ctx.stream), "launch utf8_uniform_group_kernel");
       }
       std::vector<int32_t> h_out(nu * nb * 3);
       check_hip(hipMemcpyAsync(h_out.data(), d_out->ptr, h_out.size() * 4, hipMemcpyDeviceToHost, ctx.stream), "read back");

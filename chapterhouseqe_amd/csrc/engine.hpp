@@ -28,7 +28,7 @@ hipError_t launch_cmp128(const Cmp128Params& p, hipStream_t stream);
 hipError_t launch_utf8_to_bool(const Utf8ToBoolParams& p, hipStream_t stream);
 hipError_t launch_utf8_uniform(const Utf8UniformParams& p, hipStream_t stream);
 hipError_t launch_iota_offsets(const IotaOffsetsParams& p, hipStream_t stream);
-hipError_t launch_utf8_uniform_group(const Utf8UniformGroupParams& p, hipStream_t stream);
+hipError_t launch_utf8_uniform_group(const Utf8UniformGroupParams& p, int64_t max_rows, hipStream_t stream);
 hipError_t launch_utf8_filter(const Utf8Params& p, int grid, hipStream_t stream);
 hipError_t launch_gather_i32(const GatherParams& p, hipStream_t stream);
 hipError_t launch_gather_status(const GatherStatusParams& p, hipStream_t stream);

@@ -125,20 +125,17 @@ __global__ __launch_bounds__(256) void utf8_uniform_kernel(const Utf8UniformPara
   if (__ballot(differs) != 0 && (threadIdx.x & 63) == 0) atomicOr((unsigned*)&p.out[0], 1u);
   if (blockIdx.x == 0 && threadIdx.x == 0) { p.out[1] = len; p.out[2] = first; }
 }
+// grid = (batches, slices): a batch is walked by gridDim.y workgroups (few, large batches must not be ONE workgroup's work);
+// out is zero-initialised, the flag is OR-ed in
 __global__ __launch_bounds__(256) void utf8_uniform_group_kernel(const Utf8UniformGroupParams p) {
-  __shared__ int s_differs;
   for (int64_t b = blockIdx.x; b < p.nb; b += gridDim.x) {
     const int32_t* offs = (const int32_t*)(uintptr_t)p.offsets_of[b];
     const int64_t rows = p.rows_of[b];
-    if (threadIdx.x == 0) s_differs = 0;
-    __syncthreads();
     const int32_t first = offs[0], len = rows > 0 ? offs[1] - first : 0;
     bool differs = false;
-    for (int64_t i = threadIdx.x; i < rows; i += 256) differs |= offs[i + 1] - offs[i] != len;
-    if (differs) s_differs = 1;
-    __syncthreads();
-    if (threadIdx.x == 0) { p.out[3 * b] = s_differs; p.out[3 * b + 1] = len; p.out[3 * b + 2] = first; }
-    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < rows; i += (int64_t)gridDim.y * 256) differs |= offs[i + 1] - offs[i] != len;
+    if (__ballot(differs) != 0 && (threadIdx.x & 63) == 0) atomicOr((unsigned*)&p.out[3 * b], 1u);
+    if (blockIdx.y == 0 && threadIdx.x == 0) { p.out[3 * b + 1] = len; p.out[3 * b + 2] = first; }
   }
 }
 __global__ __launch_bounds__(256) void iota_offsets_kernel(const IotaOffsetsParams p) {
@@ -158,9 +155,14 @@ hipError_t launch_utf8_uniform(const Utf8UniformParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(utf8_uniform_kernel, dim3(grid_for(p.nrows)), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
-hipError_t launch_utf8_uniform_group(const Utf8UniformGroupParams& p, hipStream_t stream) {
+hipError_t launch_utf8_uniform_group(const Utf8UniformGroupParams& p, int64_t max_rows, hipStream_t stream) {
   if (p.nb <= 0) return hipSuccess;
-  hipLaunchKernelGGL(utf8_uniform_group_kernel, dim3((unsigned)(p.nb < 65535 * 16 ? p.nb : 65535 * 16)), dim3(256), 0, stream, p);
+  const unsigned gx = (unsigned)(p.nb < 65535 * 16 ? p.nb : 65535 * 16);
+  int64_t gy = (max_rows + 16383) / 16384;             // ~64 offsets per thread ...
+  const int64_t cap = (1 << 15) / (int64_t)gx + 1;     // ... and no more than ~2^15 workgroups in all
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(utf8_uniform_group_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 hipError_t launch_iota_offsets(const IotaOffsetsParams& p, hipStream_t stream) {
