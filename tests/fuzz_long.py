@@ -149,6 +149,8 @@ def main():
     for kind in (-1, 0, 1, 2):
         c = chq.Context(0)
         c.set_option("tile_kind", kind)
+        if kind in (0, 2):   # two of the four contexts prove uniform-length string columns from 64 rows on (default: 2^24)
+            c.set_option("uniform_utf8_rows", 64)
         ctxs.append(c)
     t0 = time.time()
     stats = {"filter": 0, "value": 0, "project": 0, "group": 0, "deep": 0, "group1": 0, "errors": 0, "unsupported": 0}
