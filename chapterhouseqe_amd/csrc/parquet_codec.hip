@@ -62,6 +62,9 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
       while (!done && pos < slen && sh < 35) { const uint8_t b = src[pos++]; v |= (uint32_t)(b & 0x7f) << sh; sh += 7; done = !(b & 0x80); }
       if (!done || v != dlen) failed = true;
     }
+    // (every lane loaded the same bytes: tell the compiler, so that what steers the loops below lives in scalar registers)
+    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+    failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
     uint32_t out = 0, flushed = 0;              // bytes produced / bytes already written back (multiple of 16)
     uint32_t wlo = 0, wend = 0, wbias = 0;      // input bytes [wlo, wend) are staged: s_win[k] = input byte wbias + k
     bool got4 = false;                          // the first four output bytes were captured (while they are still in the ring)
@@ -71,13 +74,7 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
       if (tail >= flushed) for (uint32_t i = tail + lane; i < upto; i += 64) dst[i] = s_ring[i & SN_MASK];
       flushed = upto & ~15u;
     };
-    // Input window: [wlo, wend) of the input is staged in s_win.  Everything that steers the loop -- positions, lengths,
-    // offsets -- is wave-uniform and is kept in SCALAR registers: the element header is read from LDS by all lanes (same
-    // address: a broadcast) and moved to SGPRs with readfirstlane, so the parse is SALU work (one cycle per instruction
-    // instead of four, scalar branches) and only the byte movement runs on the vector unit.  The header is fetched one
-    // element AHEAD: as soon as an element's length is known the next element's position is, and its header is requested
-    // before the current element's bytes are moved -- the LDS round trips overlap instead of adding up.  (The first version
-    // parsed in vector registers and fetched on demand: ~1000 cycles per element, 28 ms for a 1 MB page of short elements.)
+    // Input window: [wlo, wend) of the input is staged in s_win (refilled about once per 4000 input bytes).
     auto refill = [&](uint32_t at) {
       wlo = at & ~3u;
       const uint32_t n = slen - wlo < SN_WIN ? slen - wlo : SN_WIN;
@@ -88,21 +85,48 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
       wbias = wlo - skew;                     // (may wrap below zero: only ever used in `pos - wbias`)
       __builtin_amdgcn_wave_barrier();        // one wave: its LDS accesses execute in order, the compiler must keep them so
     };
-    auto staged = [&](uint32_t at) { return at >= wlo && (at + 5 <= wend || wend >= slen); };
-    uint32_t n0 = 0, n1 = 0, nsh = 0;         // the two dwords holding the next header (still in flight) and its byte phase
-    auto fetch = [&](uint32_t at) {
-      const uint32_t o = at - wbias;
-      const uint32_t* w = (const uint32_t*)(s_win + (o & ~3u));
-      n0 = w[0]; n1 = w[1]; nsh = (o & 3u) * 8u;
+    // One copy element moved by the whole wave (byte i is byte (i mod off) of the `off` bytes in front of it; every source
+    // byte was final before the element started, so its at most 64 bytes are independent of each other: one lane each).
+    auto wave_copy = [&](uint32_t at, uint32_t off, uint32_t len) {
+      uint32_t i = lane;
+      if (off < len) i = (uint32_t)lane % off;
+      uint8_t b = 0;
+      if (off <= SN_RING - 64) {
+        if ((uint32_t)lane < len) b = s_ring[(at - off + i) & SN_MASK];
+      } else {                                // an offset beyond the ring: read what was written back (`out` is where the
+        flush(out);                           // finished output ends: the source lies below it; tail bytes included)
+        __threadfence();
+        if ((uint32_t)lane < len) b = __hip_atomic_load(dst + (at - off + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if ((uint32_t)lane < len) s_ring[(at + lane) & SN_MASK] = b;
     };
-    if (!failed && pos < slen) { refill(pos); fetch(pos); }
+    if (dlen > 0x7fffffffu || slen > 0x7fffffffu) failed = true;   // (Parquet page sizes are i32; keeps the sums below in 32 bits)
+    // The element chain is parsed SIXTY-FOUR INPUT BYTES AT A TIME.  Every lane decodes the header that would start at its
+    // byte (tag, length, offset: vector work, done for all 64 positions at once, most of them not element starts); the chain
+    // "element at lane c -> next element at lane c + advance(c)" is then followed by the scalar unit with readlane (a few
+    // SALU instructions per element, no memory access), which also hands every element its output position.  The bytes are
+    // moved for the whole batch of elements -- typically 20 to 30 -- together:
+    //   1. copies whose source the batch's own writes would overrun in the ring (offsets near 64 KiB) go first, in order;
+    //   2. every literal byte of the batch lies in the 64-byte input slice: lane p writes its byte to its place;
+    //   3. the other copies run one LANE per element, in rounds: a copy is ready once its source ends at or below the first
+    //      unfinished copy's output (everything below that is final).  Matches mostly point far back, so one or two rounds
+    //      do; a chain of copies that each read the previous one's bytes degrades to one element per round.
+    // (The version before this one walked the chain one element at a time: ~1400 cycles of dependent LDS round trips and
+    // issue latency per element with one wave per SIMD, 60+ ms for a 1 MB page of short elements.)
     while (!failed && pos < slen && out < dlen) {
-      // header bytes of the element at `pos`: tag, b1 .. b4 (bytes past the input are ignored below)
-      const uint64_t hv = (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)n1) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)n0)) >> nsh;
-      const uint32_t tag = (uint32_t)hv & 0xffu;
-      const uint32_t b14 = (uint32_t)(hv >> 8);               // b1 | b2 << 8 | b3 << 16 | b4 << 24
+      if (!(pos >= wlo && (pos + 72 <= wend || wend >= slen))) refill(pos);
+      const uint32_t p = pos + lane;            // this lane's input byte
+      uint32_t tag = 0, b14 = 0;
+      if (p < slen) {
+        const uint32_t o = p - wbias;
+        const uint32_t* w = (const uint32_t*)(s_win + (o & ~3u));
+        const uint64_t hv = (((uint64_t)w[1] << 32) | w[0]) >> ((o & 3u) * 8u);
+        tag = (uint32_t)hv & 0xffu;
+        b14 = (uint32_t)(hv >> 8);              // b1 | b2 << 8 | b3 << 16 | b4 << 24
+      }
       const uint32_t kind = tag & 3u;
       uint32_t len, off = 0, hdr;
+      bool bad = false;                         // this header cannot be an element (only matters if the chain lands on it)
       if (kind == 0) {
         len = tag >> 2; hdr = 1;
         if (len >= 60) {
@@ -110,40 +134,52 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
           len = nb == 4 ? b14 : (b14 & ((1u << (8 * nb)) - 1u));
           hdr = 1 + nb;
         }
-        if (len == 0xffffffffu || pos + hdr > slen) { failed = true; break; }
+        bad = len == 0xffffffffu || p + hdr > slen;
         len += 1;
-        if (len > slen - pos - hdr || len > dlen - out) { failed = true; break; }
+        if (!bad) bad = len > slen - p - hdr;
       } else {
         if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | (b14 & 0xffu); hdr = 2; }
         else if (kind == 2) { len = (tag >> 2) + 1; off = b14 & 0xffffu; hdr = 3; }
         else { len = (tag >> 2) + 1; off = b14; hdr = 5; }
-        if (pos + hdr > slen || off == 0 || off > out || len > dlen - out) { failed = true; break; }
+        bad = p + hdr > slen;
       }
-      const uint32_t data = pos + hdr;                          // a literal's bytes start here
-      const uint32_t next = kind == 0 ? data + len : data;      // the next element
-      const bool ahead = next < slen && staged(next);
-      if (ahead) fetch(next);
-      if (kind == 0) {
-        // ---- literal ----
+      const uint32_t adv = kind != 0 ? hdr : (bad || len > 64 ? 4096u : hdr + len);   // input bytes to the next element
+      // ---- the chain (scalar): element starts M, their output positions opos, the batch ends at input byte `cur` ----
+      uint64_t M = 0;
+      uint32_t cur = 0, o_end = out, opos = 0;
+      const uint32_t lim = slen - pos < 64 ? slen - pos : 64;
+      while (cur < lim) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)cur);
+        if (cur + a > 64) break;                // (a long literal, or one that crosses the slice: it starts the next batch)
+        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)cur);
+        if ((uint32_t)lane == cur) opos = o_end;
+        M |= 1ull << cur;
+        o_end += l;                             // (each length is at most 64: no overflow)
+        cur += a;
+      }
+      if (M == 0) {
+        // ---- the element at `pos` is a literal of more than ~60 bytes (or a damaged header): moved on its own ----
+        if (__builtin_amdgcn_readfirstlane((int)bad)) { failed = true; break; }
+        const uint32_t llen = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+        const uint32_t data = pos + (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr);
+        if (llen > dlen - out) { failed = true; break; }
         uint32_t done = 0;
-        if (data + len <= wend && data >= wlo) {
-          // a literal that lies inside the staged input window -- the common case by far: text-like data alternates copies
-          // with literals of a few bytes -- moves LDS -> LDS (from HBM it would cost a memory round trip per element)
+        if (data + llen <= wend && data >= wlo) {   // inside the staged input: LDS -> LDS
           const uint32_t sbase = data - wbias;
-          for (; done < len; done += 64) {
+          for (; done < llen; done += 64) {
             const uint32_t i = done + lane;
             uint8_t b = 0;
-            if (i < len) b = s_win[sbase + i];
-            if (i < len) s_ring[(out + i) & SN_MASK] = b;
+            if (i < llen) b = s_win[sbase + i];
+            if (i < llen) s_ring[(out + i) & SN_MASK] = b;
           }
-          done = len;
+          done = llen;
           if (!got4 && out + done >= 4) { first4 = *(const uint32_t*)s_ring; got4 = true; }
           if (out + done - flushed >= SN_FLUSH) flush((out + done) & ~15u);
         }
         // otherwise HBM -> ring, 512 bytes per round (eight byte loads per lane in flight); rounds are interleaved with
         // write-backs so that a long literal (incompressible data: one literal per 64 KiB block) never overruns the ring
-        while (done < len) {
-          const uint32_t n = len - done < 512 ? len - done : 512;
+        while (done < llen) {
+          const uint32_t n = llen - done < 512 ? llen - done : 512;
           uint8_t v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) { const uint32_t i = u * 64 + lane; v[u] = i < n ? src[data + done + i] : 0; }
@@ -153,27 +189,63 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
           if (!got4 && out + done >= 4) { first4 = *(const uint32_t*)s_ring; got4 = true; }   // (at most 512 bytes in: still there)
           if (out + done - flushed >= SN_FLUSH) flush((out + done) & ~15u);
         }
-        out += len;
-      } else {
-        // ---- copy: byte i is byte (i mod off) of the `off` bytes in front of it -- every source byte was final before
-        // this element started, so the (at most 64) bytes are independent of each other: one lane each ----
-        uint32_t i = lane;
-        if (off < len) i = (uint32_t)lane % off;
-        uint8_t b = 0;
-        if (off <= SN_RING - 64) {
-          if ((uint32_t)lane < len) b = s_ring[(out - off + i) & SN_MASK];
-        } else {                                // an offset beyond the ring: read what was written back (never produced by
-          flush(out);                           // the snappy library; the tail bytes of a partial 16-byte group included)
-          __threadfence();
-          if ((uint32_t)lane < len) b = __hip_atomic_load(dst + (out - off + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if ((uint32_t)lane < len) s_ring[(out + lane) & SN_MASK] = b;
-        out += len;
-        if (!got4 && out >= 4) { first4 = *(const uint32_t*)s_ring; got4 = true; }   // (a copy is at most 64 bytes: still there)
-        if (out - flushed >= SN_FLUSH) flush(out & ~15u);
+        out += llen;
+        pos = data + llen;
+        continue;
       }
-      pos = next;
-      if (!ahead && pos < slen && out < dlen) { refill(pos); fetch(pos); }   // (the window is only replaced once the element that read from it is done)
+      // ---- the batch: elements at the lanes of M, input [pos, pos + cur), output [out, o_end) ----
+      const bool start = (M >> lane) & 1ull;
+      const bool copy = start && kind != 0;
+      if (__builtin_amdgcn_ballot_w64(start && (bad || opos + len > dlen || (kind != 0 && (off == 0 || off > opos))))) { failed = true; break; }
+      // 1. a later element of the batch writes ring slots up to o_end: what lies 64 KiB below that is overwritten.  Copies
+      //    that read from there (their source is older than the batch, so it is final) are moved first, in element order
+      {
+        uint64_t fm = __builtin_amdgcn_ballot_w64(copy && off > SN_RING - (o_end - opos));
+        while (fm) {
+          const int e = __builtin_ctzll(fm);
+          fm &= fm - 1;
+          wave_copy((uint32_t)__builtin_amdgcn_readlane((int)opos, e), (uint32_t)__builtin_amdgcn_readlane((int)off, e),
+                    (uint32_t)__builtin_amdgcn_readlane((int)len, e));
+        }
+      }
+      const bool near = copy && off <= SN_RING - (o_end - opos);
+      // 2. literal bytes: input byte p belongs to the last element starting at or below it
+      {
+        const uint64_t below = M & ((2ull << lane) - 1ull);          // (bit 0 of M is set: the batch starts at lane 0)
+        const int e = 63 - __builtin_clzll(below);
+        const uint32_t e_opos = (uint32_t)__shfl((int)opos, e, 64);
+        const uint32_t e_hk = (uint32_t)__shfl((int)(hdr | (kind << 4)), e, 64);
+        const uint32_t first = (uint32_t)e + (e_hk & 15u);         // the element's first data byte
+        if ((uint32_t)lane < cur && (e_hk >> 4) == 0 && (uint32_t)lane >= first) s_ring[(e_opos + (uint32_t)lane - first) & SN_MASK] = (uint8_t)tag;
+      }
+      // 3. the copies, one lane per element
+      {
+        uint64_t un = __builtin_amdgcn_ballot_w64(near);
+        const uint32_t src0 = opos - off;
+        const uint32_t src_end = src0 + (off < len ? off : len);     // its distinct source bytes end here
+        while (un) {
+          const uint32_t F = (uint32_t)__builtin_amdgcn_readlane((int)opos, __builtin_ctzll(un));   // below F the output is final
+          const bool ready = ((un >> lane) & 1ull) && src_end <= F;  // (the first unfinished copy always is)
+          un &= ~__builtin_amdgcn_ballot_w64(ready);
+          uint32_t r = 0;                                            // i mod off, kept incrementally
+          for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(ready && j < len); j += 8) {
+            uint8_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+              v[u] = 0;
+              if (ready && j + u < len) v[u] = s_ring[(src0 + r) & SN_MASK];
+              r = r + 1 == off ? 0 : r + 1;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+              if (ready && j + u < len) s_ring[(opos + j + u) & SN_MASK] = v[u];
+          }
+        }
+      }
+      pos += cur;
+      out = o_end;
+      if (!got4 && out >= 4) { first4 = *(const uint32_t*)s_ring; got4 = true; }   // (a batch makes at most 4 KiB: still there)
+      if (out - flushed >= SN_FLUSH) flush(out & ~15u);
     }
     if (!failed && (out != dlen || pos != slen)) failed = true;
     if (!failed) flush(out);

@@ -169,6 +169,84 @@ def test_range_reader_fetches_the_footer_and_only_the_chunks_it_decodes(ctx):
         chq.ParquetFile(None, reader=lambda off, ln: raw[off:off + ln - 1], size=len(raw))
 
 
+def snappy_elements(raw: bytes):
+    """(kind, length, offset) of every element of a raw snappy stream (format_description.txt) -- used to check that the data
+    below really makes the compressor emit the elements the test is about"""
+    pos, sh, n = 0, 0, 0
+    while True:
+        b = raw[pos]; pos += 1
+        n |= (b & 0x7f) << sh; sh += 7
+        if not b & 0x80:
+            break
+    out = []
+    while pos < len(raw):
+        tag = raw[pos]; kind = tag & 3
+        if kind == 0:
+            ln = tag >> 2; hdr = 1
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(raw[pos + 1:pos + 1 + nb], "little"); hdr = 1 + nb
+            ln += 1
+            out.append((0, ln, 0)); pos += hdr + ln
+        elif kind == 1:
+            out.append((1, ((tag >> 2) & 7) + 4, ((tag >> 5) << 8) | raw[pos + 1])); pos += 2
+        elif kind == 2:
+            out.append((2, (tag >> 2) + 1, int.from_bytes(raw[pos + 1:pos + 3], "little"))); pos += 3
+        else:
+            out.append((3, (tag >> 2) + 1, int.from_bytes(raw[pos + 1:pos + 5], "little"))); pos += 5
+    return n, out
+
+
+def test_snappy_elements_the_batched_parser_must_order(ctx):
+    """the inflate kernel moves the elements of 64 input bytes together (csrc/parquet_codec.hip): copies that read what an
+    earlier copy of the same batch wrote (chains of period-p runs), copies whose offset is close to the 64 KiB of history the
+    ring holds (moved before the batch's own writes overrun their source), offsets beyond the ring (read back from HBM),
+    literals too long for a batch, and a random mix of all of them.  The page is a required Int64 column's PLAIN values, so
+    the stream the compressor sees is exactly these bytes"""
+    rng = np.random.default_rng(2024)
+    parts = []
+    def rnd(k):
+        return rng.integers(0, 256, k, dtype=np.uint8).tobytes()
+    # one 64 KiB block per far offset: a key, a run (which leaves the compressor's match table alone), the key again
+    for gap in (65536 - 48, 65440, 65473, 65400, 63000, 61500, 61000, 65487):
+        key = rnd(48)
+        block = key + bytes(gap - 48) + key
+        parts.append(block + rnd(65536 - len(block)) if len(block) < 65536 else block[:65536])
+    # chains: runs of every short period (each copy reads the bytes the previous one wrote), cut by literals of odd lengths
+    for period in (1, 2, 3, 5, 7, 8, 11, 13, 24, 63, 64, 65, 100):
+        unit = rnd(period)
+        parts.append(unit * (1 + 3000 // period) + rnd(int(rng.integers(1, 9))))
+    # a random mix: short literals, repeats of earlier bytes at any distance, runs, now and then a long literal
+    mix = bytearray(rnd(200))
+    while len(mix) < 3_000_000:
+        c = rng.integers(0, 10)
+        if c < 4:
+            mix += rnd(int(rng.integers(1, 12)))
+        elif c < 8:
+            back = int(rng.integers(1, min(len(mix), 70000)))
+            k = int(rng.integers(4, 80))
+            at = len(mix) - back
+            mix += mix[at:at + k]
+        elif c < 9:
+            unit = rnd(int(rng.integers(1, 12)))
+            mix += unit * int(rng.integers(2, 40))
+        else:
+            mix += rnd(int(rng.integers(60, 400)))
+    parts.append(bytes(mix))
+    stream = b"".join(parts)
+    stream += bytes(-len(stream) % 8)
+    n_out, elements = snappy_elements(pa.Codec("snappy").compress(stream, asbytes=True))
+    assert n_out == len(stream)
+    offs = np.array([e[2] for e in elements if e[0]]); lens = np.array([e[1] for e in elements if e[0]])
+    assert (offs > 65472).any() and ((offs > 61400) & (offs <= 65472)).sum() >= 3          # beyond the ring / moved first
+    assert (offs < lens).sum() > 100 and any(e[0] == 0 and e[1] > 64 for e in elements)   # self-overlapping copies, long literals
+    assert len(elements) > 40_000
+    values = np.frombuffer(stream, dtype=np.int64)
+    t = pa.table({"v": pa.array(values)}, schema=pa.schema([pa.field("v", pa.int64(), nullable=False)]))
+    for kw in [dict(data_page_size=1 << 26), dict(data_page_size=1 << 20), dict(data_page_size=70_000), dict(data_page_version="2.0", data_page_size=1 << 26)]:
+        check(write_bytes(t, compression="snappy", use_dictionary=False, **kw), ctx)
+
+
 def test_damaged_snappy_pages_are_reported(ctx):
     """compressed bytes overwritten: offsets beyond the output so far, literals running past the page, a wrong uncompressed
     length -- the inflate kernel bounds every element and the call names the column"""
