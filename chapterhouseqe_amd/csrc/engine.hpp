@@ -133,6 +133,7 @@ struct Context {
   int64_t opt_group_bits = 1;       // wave-packed device groups with validity bitmaps / Boolean columns take the one-launch path (0: joined first)
   int64_t opt_uniform_utf8_rows = 1 << 24;   // batches from this size on (below it the extra pass and its read-back cost more than the copy saves): Utf8 columns whose values all have one length are filtered as fixed-width columns (0: never)
   int64_t opt_parquet_page_rows = 65536;   // chq_record_to_parquet: rows per data page (multiples of 4096; at most 64 pages per chunk)
+  int64_t opt_snappy_blocks = 1;           // Parquet scan: snappy pages of 3+ blocks of 64 KiB are inflated block by block (0: one wave per page; 2: the blocks give up -- tests)
   int64_t opt_group_fold = 1;       // device-resident groups with short-string Utf8 columns: filtered straight out of the batches (0: joined first)
   int64_t opt_fold_utf8 = 1;        // short-string Utf8 columns are filtered inside filter_fused_kernel (0: always the separate Utf8 pass)
   int64_t opt_stash = -1;           // predicate input columns kept in LDS between the filter kernel's phases: -1 = as many as the tile kind has slots

@@ -33,136 +33,143 @@ constexpr uint32_t SN_FLUSH = 16384;        // ring -> HBM once this much is pen
 
 __device__ __forceinline__ void codec_error(uint32_t* err) { atomicMax(err, (uint32_t)PQ_ERR_CODEC); }
 
-}  // namespace
+// The wave's inclusive prefix sum (DPP: shifts inside the rows of 16 lanes, then the row totals broadcast to the rows behind).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1 (a lane without a source adds 0)
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
 
-// One wave per job.  job.raw: the chunk as it lies in the file; job.image: the uncompressed image (both padded by 64 bytes).
-__global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[SN_RING];
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[SN_WIN + 32];
-  const int lane = threadIdx.x;
-  const PqCodecJob job = p.jobs[blockIdx.x];
-  const uint8_t* src = job.raw + job.src_at;
-  uint8_t* dst = job.image + job.dst_at;        // (dst_at is a multiple of 16)
-  const uint32_t slen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.src_len), dlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.dst_len);
+enum { SN_FULL = 0, SN_INDEX = 1 };
+
+// One raw snappy stream (`preamble`: it starts with its uncompressed length, which must be dlen), walked by one wave.
+//   SN_FULL   the bytes are produced: src[0, slen) -> dst[0, dlen); first4 = the first four bytes of output.
+//   SN_INDEX  nothing is moved: the element chain is walked only to learn where in the input every 64 KiB BLOCK of output
+//             starts (index[1 + k] = input position of the element that produces output byte k * 65536).  The snappy
+//             compressor works on 64 KiB blocks of input one at a time -- no element straddles a block boundary and no copy
+//             reaches into the previous block -- so with that table the blocks of a page are inflated by one wave EACH
+//             (the walk costs a few scalar instructions per element, the moves an LDS round trip or more).  The format
+//             does not promise it: `aligned` comes back false if an element straddles a boundary, a block job that meets
+//             an offset reaching below its block gives up, and either way the page is then redone by one wave (FINISH).
+// Returns true if the stream is damaged.
+template <int MODE>
+__device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t slen, uint8_t* dst, const uint32_t dlen, const bool preamble,
+                                               uint32_t* index, bool& aligned, uint32_t& first4, uint8_t* s_ring, uint8_t* s_win, const int lane) {
   bool failed = false;
-  uint32_t first4 = 0;
-
-  if (job.codec == PQ_CODEC_STORED) {           // a page (or the level bytes of a V2 page) that lies uncompressed in the file
-    if (slen != dlen) failed = true;
-    else {
-      for (uint32_t i = lane * 16u; i + 16 <= dlen; i += 64 * 16) { uint4 w; __builtin_memcpy(&w, src + i, 16); *(uint4*)(dst + i) = w; }
-      for (uint32_t i = (dlen & ~15u) + lane; i < dlen; i += 64) dst[i] = src[i];
-      if (dlen >= 4) { __builtin_memcpy(&first4, src, 4); }
+  uint32_t pos = 0;                           // next input byte
+  // ---- preamble: the uncompressed length must be what the page header promised ----
+  if (preamble) {
+    uint32_t v = 0; int sh = 0; bool done = false;
+    while (!done && pos < slen && sh < 35) { const uint8_t b = src[pos++]; v |= (uint32_t)(b & 0x7f) << sh; sh += 7; done = !(b & 0x80); }
+    if (!done || v != dlen) failed = true;
+  }
+  // (every lane loaded the same bytes: tell the compiler, so that what steers the loops below lives in scalar registers)
+  pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+  failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
+  uint32_t out = 0, flushed = 0;              // bytes produced / bytes already written back (multiple of 16)
+  uint32_t wlo = 0, wend = 0, wbias = 0;      // input bytes [wlo, wend) are staged: s_win[k] = input byte wbias + k
+  bool got4 = false;                          // the first four output bytes were captured (while they are still in the ring)
+  auto flush = [&](uint32_t upto) {           // ring [flushed, upto) -> HBM; upto is a multiple of 16 (or the end)
+    for (uint32_t i = flushed + lane * 16u; i + 16 <= upto; i += 64 * 16) *(uint4*)(dst + i) = *(const uint4*)(s_ring + (i & SN_MASK));
+    const uint32_t tail = upto & ~15u;
+    if (tail >= flushed) for (uint32_t i = tail + lane; i < upto; i += 64) dst[i] = s_ring[i & SN_MASK];
+    flushed = upto & ~15u;
+  };
+  // Input window: [wlo, wend) of the input is staged in s_win (refilled about once per 4000 input bytes).
+  auto refill = [&](uint32_t at) {
+    wlo = at & ~3u;
+    const uint32_t n = slen - wlo < SN_WIN ? slen - wlo : SN_WIN;
+    const uint32_t skew = (uint32_t)((uintptr_t)(src + wlo) & 3);
+    const uint32_t* g = (const uint32_t*)(src + wlo - skew);   // aligned dword loads (the raw buffer is padded by 64 bytes)
+    for (uint32_t i = lane; i < (n + skew + 3) / 4 + 2; i += 64) ((uint32_t*)s_win)[i] = g[i];
+    wend = wlo + n;
+    wbias = wlo - skew;                     // (may wrap below zero: only ever used in `pos - wbias`)
+    __builtin_amdgcn_wave_barrier();        // one wave: its LDS accesses execute in order, the compiler must keep them so
+  };
+  // One copy element moved by the whole wave (byte i is byte (i mod off) of the `off` bytes in front of it; every source
+  // byte was final before the element started, so its at most 64 bytes are independent of each other: one lane each).
+  auto wave_copy = [&](uint32_t at, uint32_t off, uint32_t len) {
+    uint32_t i = lane;
+    if (off < len) i = (uint32_t)lane % off;
+    uint8_t b = 0;
+    if (off <= SN_RING - 64) {
+      if ((uint32_t)lane < len) b = s_ring[(at - off + i) & SN_MASK];
+    } else {                                // an offset beyond the ring: read what was written back (`out` is where the
+      flush(out);                           // finished output ends: the source lies below it; tail bytes included)
+      __threadfence();
+      if ((uint32_t)lane < len) b = __hip_atomic_load(dst + (at - off + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  } else if (job.codec == PQ_CODEC_SNAPPY) {
-    uint32_t pos = 0;                           // next input byte
-    // ---- preamble: the uncompressed length must be what the page header promised ----
-    {
-      uint32_t v = 0; int sh = 0; bool done = false;
-      while (!done && pos < slen && sh < 35) { const uint8_t b = src[pos++]; v |= (uint32_t)(b & 0x7f) << sh; sh += 7; done = !(b & 0x80); }
-      if (!done || v != dlen) failed = true;
+    if ((uint32_t)lane < len) s_ring[(at + lane) & SN_MASK] = b;
+  };
+  if (dlen > 0x7fffffffu || slen > 0x7fffffffu) failed = true;   // (Parquet page sizes are i32; keeps the sums below in 32 bits)
+  // The element chain is parsed SIXTY-FOUR INPUT BYTES AT A TIME.  Every lane decodes the header that would start at its
+  // byte (tag, length, offset: vector work, done for all 64 positions at once, most of them not element starts); the chain
+  // "element at lane c -> next element at lane c + advance(c)" is then followed by the scalar unit with readlane (a few
+  // SALU instructions per element, no memory access), which also hands every element its output position.  The bytes are
+  // moved for the whole batch of elements -- typically 20 to 30 -- together:
+  //   1. copies whose source the batch's own writes would overrun in the ring (offsets near 64 KiB) go first, in order;
+  //   2. every literal byte of the batch lies in the 64-byte input slice: lane p writes its byte to its place;
+  //   3. the other copies run one LANE per element, in rounds: a copy is ready once its source ends at or below the first
+  //      unfinished copy's output (everything below that is final).  Matches mostly point far back, so one or two rounds
+  //      do; a chain of copies that each read the previous one's bytes degrades to one element per round.
+  // (The version before this one walked the chain one element at a time: ~1400 cycles of dependent LDS round trips and
+  // issue latency per element with one wave per SIMD, 60+ ms for a 1 MB page of short elements.)
+  while (!failed && pos < slen && out < dlen) {
+    if (!(pos >= wlo && (pos + 72 <= wend || wend >= slen))) refill(pos);
+    const uint32_t p = pos + lane;            // this lane's input byte
+    uint32_t tag = 0, b14 = 0;
+    if (p < slen) {
+      const uint32_t o = p - wbias;
+      const uint32_t* w = (const uint32_t*)(s_win + (o & ~3u));
+      const uint64_t hv = (((uint64_t)w[1] << 32) | w[0]) >> ((o & 3u) * 8u);
+      tag = (uint32_t)hv & 0xffu;
+      b14 = (uint32_t)(hv >> 8);              // b1 | b2 << 8 | b3 << 16 | b4 << 24
     }
-    // (every lane loaded the same bytes: tell the compiler, so that what steers the loops below lives in scalar registers)
-    pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-    failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
-    uint32_t out = 0, flushed = 0;              // bytes produced / bytes already written back (multiple of 16)
-    uint32_t wlo = 0, wend = 0, wbias = 0;      // input bytes [wlo, wend) are staged: s_win[k] = input byte wbias + k
-    bool got4 = false;                          // the first four output bytes were captured (while they are still in the ring)
-    auto flush = [&](uint32_t upto) {           // ring [flushed, upto) -> HBM; upto is a multiple of 16 (or the end)
-      for (uint32_t i = flushed + lane * 16u; i + 16 <= upto; i += 64 * 16) *(uint4*)(dst + i) = *(const uint4*)(s_ring + (i & SN_MASK));
-      const uint32_t tail = upto & ~15u;
-      if (tail >= flushed) for (uint32_t i = tail + lane; i < upto; i += 64) dst[i] = s_ring[i & SN_MASK];
-      flushed = upto & ~15u;
-    };
-    // Input window: [wlo, wend) of the input is staged in s_win (refilled about once per 4000 input bytes).
-    auto refill = [&](uint32_t at) {
-      wlo = at & ~3u;
-      const uint32_t n = slen - wlo < SN_WIN ? slen - wlo : SN_WIN;
-      const uint32_t skew = (uint32_t)((uintptr_t)(src + wlo) & 3);
-      const uint32_t* g = (const uint32_t*)(src + wlo - skew);   // aligned dword loads (the raw buffer is padded by 64 bytes)
-      for (uint32_t i = lane; i < (n + skew + 3) / 4 + 2; i += 64) ((uint32_t*)s_win)[i] = g[i];
-      wend = wlo + n;
-      wbias = wlo - skew;                     // (may wrap below zero: only ever used in `pos - wbias`)
-      __builtin_amdgcn_wave_barrier();        // one wave: its LDS accesses execute in order, the compiler must keep them so
-    };
-    // One copy element moved by the whole wave (byte i is byte (i mod off) of the `off` bytes in front of it; every source
-    // byte was final before the element started, so its at most 64 bytes are independent of each other: one lane each).
-    auto wave_copy = [&](uint32_t at, uint32_t off, uint32_t len) {
-      uint32_t i = lane;
-      if (off < len) i = (uint32_t)lane % off;
-      uint8_t b = 0;
-      if (off <= SN_RING - 64) {
-        if ((uint32_t)lane < len) b = s_ring[(at - off + i) & SN_MASK];
-      } else {                                // an offset beyond the ring: read what was written back (`out` is where the
-        flush(out);                           // finished output ends: the source lies below it; tail bytes included)
-        __threadfence();
-        if ((uint32_t)lane < len) b = __hip_atomic_load(dst + (at - off + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t kind = tag & 3u;
+    uint32_t len, off = 0, hdr;
+    bool bad = false;                         // this header cannot be an element (only matters if the chain lands on it)
+    if (kind == 0) {
+      len = tag >> 2; hdr = 1;
+      if (len >= 60) {
+        const uint32_t nb = len - 59;
+        len = nb == 4 ? b14 : (b14 & ((1u << (8 * nb)) - 1u));
+        hdr = 1 + nb;
       }
-      if ((uint32_t)lane < len) s_ring[(at + lane) & SN_MASK] = b;
-    };
-    if (dlen > 0x7fffffffu || slen > 0x7fffffffu) failed = true;   // (Parquet page sizes are i32; keeps the sums below in 32 bits)
-    // The element chain is parsed SIXTY-FOUR INPUT BYTES AT A TIME.  Every lane decodes the header that would start at its
-    // byte (tag, length, offset: vector work, done for all 64 positions at once, most of them not element starts); the chain
-    // "element at lane c -> next element at lane c + advance(c)" is then followed by the scalar unit with readlane (a few
-    // SALU instructions per element, no memory access), which also hands every element its output position.  The bytes are
-    // moved for the whole batch of elements -- typically 20 to 30 -- together:
-    //   1. copies whose source the batch's own writes would overrun in the ring (offsets near 64 KiB) go first, in order;
-    //   2. every literal byte of the batch lies in the 64-byte input slice: lane p writes its byte to its place;
-    //   3. the other copies run one LANE per element, in rounds: a copy is ready once its source ends at or below the first
-    //      unfinished copy's output (everything below that is final).  Matches mostly point far back, so one or two rounds
-    //      do; a chain of copies that each read the previous one's bytes degrades to one element per round.
-    // (The version before this one walked the chain one element at a time: ~1400 cycles of dependent LDS round trips and
-    // issue latency per element with one wave per SIMD, 60+ ms for a 1 MB page of short elements.)
-    while (!failed && pos < slen && out < dlen) {
-      if (!(pos >= wlo && (pos + 72 <= wend || wend >= slen))) refill(pos);
-      const uint32_t p = pos + lane;            // this lane's input byte
-      uint32_t tag = 0, b14 = 0;
-      if (p < slen) {
-        const uint32_t o = p - wbias;
-        const uint32_t* w = (const uint32_t*)(s_win + (o & ~3u));
-        const uint64_t hv = (((uint64_t)w[1] << 32) | w[0]) >> ((o & 3u) * 8u);
-        tag = (uint32_t)hv & 0xffu;
-        b14 = (uint32_t)(hv >> 8);              // b1 | b2 << 8 | b3 << 16 | b4 << 24
-      }
-      const uint32_t kind = tag & 3u;
-      uint32_t len, off = 0, hdr;
-      bool bad = false;                         // this header cannot be an element (only matters if the chain lands on it)
-      if (kind == 0) {
-        len = tag >> 2; hdr = 1;
-        if (len >= 60) {
-          const uint32_t nb = len - 59;
-          len = nb == 4 ? b14 : (b14 & ((1u << (8 * nb)) - 1u));
-          hdr = 1 + nb;
-        }
-        bad = len == 0xffffffffu || p + hdr > slen;
-        len += 1;
-        if (!bad) bad = len > slen - p - hdr;
+      bad = len == 0xffffffffu || p + hdr > slen;
+      len += 1;
+      if (!bad) bad = len > slen - p - hdr;
+    } else {
+      if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | (b14 & 0xffu); hdr = 2; }
+      else if (kind == 2) { len = (tag >> 2) + 1; off = b14 & 0xffffu; hdr = 3; }
+      else { len = (tag >> 2) + 1; off = b14; hdr = 5; }
+      bad = p + hdr > slen;
+    }
+    const uint32_t adv = kind != 0 ? hdr : (bad || len > 64 ? 4096u : hdr + len);   // input bytes to the next element
+    // ---- the chain (scalar): element starts M; the batch ends at input byte `cur` ----
+    const uint32_t lim = slen - pos < 64 ? slen - pos : 64;
+    // (an element must END inside the slice -- lane + adv <= 63 -- so that `cur` stays a lane number and the loop below
+    // has one test per element; a longer literal, or one that reaches the slice's end, starts the next batch)
+    const uint64_t fits = __builtin_amdgcn_ballot_w64((uint32_t)lane < lim && (uint32_t)lane + adv <= 63);
+    uint64_t M = 0;
+    uint32_t cur = 0;
+    while ((fits >> cur) & 1ull) {
+      M |= 1ull << cur;
+      cur += (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)cur);
+    }
+    if (M == 0) {
+      // ---- the element at `pos` is a literal that does not end inside the slice (or a damaged header): moved on its own ----
+      if (__builtin_amdgcn_readfirstlane((int)bad)) { failed = true; break; }
+      const uint32_t llen = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+      const uint32_t data = pos + (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr);
+      if (llen > dlen - out) { failed = true; break; }
+      if (MODE == SN_INDEX) {                     // where the 64 KiB blocks of output start in the input
+        if ((out & 0xffffu) == 0 && lane == 0) index[1 + (out >> 16)] = pos;
+        if ((out ^ (out + llen - 1)) >> 16) aligned = false;
       } else {
-        if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | (b14 & 0xffu); hdr = 2; }
-        else if (kind == 2) { len = (tag >> 2) + 1; off = b14 & 0xffffu; hdr = 3; }
-        else { len = (tag >> 2) + 1; off = b14; hdr = 5; }
-        bad = p + hdr > slen;
-      }
-      const uint32_t adv = kind != 0 ? hdr : (bad || len > 64 ? 4096u : hdr + len);   // input bytes to the next element
-      // ---- the chain (scalar): element starts M, their output positions opos, the batch ends at input byte `cur` ----
-      uint64_t M = 0;
-      uint32_t cur = 0, o_end = out, opos = 0;
-      const uint32_t lim = slen - pos < 64 ? slen - pos : 64;
-      while (cur < lim) {
-        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)cur);
-        if (cur + a > 64) break;                // (a long literal, or one that crosses the slice: it starts the next batch)
-        const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)cur);
-        if ((uint32_t)lane == cur) opos = o_end;
-        M |= 1ull << cur;
-        o_end += l;                             // (each length is at most 64: no overflow)
-        cur += a;
-      }
-      if (M == 0) {
-        // ---- the element at `pos` is a literal of more than ~60 bytes (or a damaged header): moved on its own ----
-        if (__builtin_amdgcn_readfirstlane((int)bad)) { failed = true; break; }
-        const uint32_t llen = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
-        const uint32_t data = pos + (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr);
-        if (llen > dlen - out) { failed = true; break; }
         uint32_t done = 0;
         if (data + llen <= wend && data >= wlo) {   // inside the staged input: LDS -> LDS
           const uint32_t sbase = data - wbias;
@@ -189,14 +196,23 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
           if (!got4 && out + done >= 4) { first4 = *(const uint32_t*)s_ring; got4 = true; }   // (at most 512 bytes in: still there)
           if (out + done - flushed >= SN_FLUSH) flush((out + done) & ~15u);
         }
-        out += llen;
-        pos = data + llen;
-        continue;
       }
-      // ---- the batch: elements at the lanes of M, input [pos, pos + cur), output [out, o_end) ----
-      const bool start = (M >> lane) & 1ull;
-      const bool copy = start && kind != 0;
-      if (__builtin_amdgcn_ballot_w64(start && (bad || opos + len > dlen || (kind != 0 && (off == 0 || off > opos))))) { failed = true; break; }
+      out += llen;
+      pos = data + llen;
+      continue;
+    }
+    // output positions: a wave prefix sum of the lengths at the element starts (each at most 64: no overflow)
+    const bool start = (M >> lane) & 1ull;
+    const uint32_t incl = wave_inclusive_sum(start ? len : 0u);
+    const uint32_t opos = out + incl - (start ? len : 0u);
+    const uint32_t o_end = out + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    // ---- the batch: elements at the lanes of M, input [pos, pos + cur), output [out, o_end) ----
+    const bool copy = start && kind != 0;
+    if (__builtin_amdgcn_ballot_w64(start && (bad || opos + len > dlen || (MODE == SN_FULL && kind != 0 && (off == 0 || off > opos))))) { failed = true; break; }
+    if (MODE == SN_INDEX) {
+      if (start && (opos & 0xffffu) == 0) index[1 + (opos >> 16)] = pos + (uint32_t)lane;
+      if (__builtin_amdgcn_ballot_w64(start && ((opos ^ (opos + len - 1)) >> 16) != 0)) aligned = false;
+    } else {
       // 1. a later element of the batch writes ring slots up to o_end: what lies 64 KiB below that is overwritten.  Copies
       //    that read from there (their source is older than the batch, so it is final) are moved first, in element order
       {
@@ -242,13 +258,72 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
           }
         }
       }
-      pos += cur;
-      out = o_end;
+    }
+    pos += cur;
+    out = o_end;
+    if (MODE == SN_FULL) {
       if (!got4 && out >= 4) { first4 = *(const uint32_t*)s_ring; got4 = true; }   // (a batch makes at most 4 KiB: still there)
       if (out - flushed >= SN_FLUSH) flush(out & ~15u);
     }
-    if (!failed && (out != dlen || pos != slen)) failed = true;
-    if (!failed) flush(out);
+  }
+  if (!failed && (out != dlen || pos != slen)) failed = true;
+  if (MODE == SN_FULL && !failed) flush(out);
+  return failed;
+}
+
+}  // namespace
+
+// One wave per job.  job.raw: the chunk as it lies in the file; job.image: the uncompressed image (both padded by 64 bytes).
+__global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[SN_RING];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[SN_WIN + 32];
+  const int lane = threadIdx.x;
+  const PqCodecJob job = p.jobs[blockIdx.x];
+  const uint8_t* src = job.raw + job.src_at;
+  uint8_t* dst = job.image + job.dst_at;        // (dst_at is a multiple of 16)
+  uint32_t slen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.src_len), dlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.dst_len);
+  const uint32_t codec = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.codec);
+  bool failed = false, aligned = true;
+  uint32_t first4 = 0;
+
+  if (codec == PQ_CODEC_STORED) {               // a page (or the level bytes of a V2 page) that lies uncompressed in the file
+    if (slen != dlen) failed = true;
+    else {
+      for (uint32_t i = lane * 16u; i + 16 <= dlen; i += 64 * 16) { uint4 w; __builtin_memcpy(&w, src + i, 16); *(uint4*)(dst + i) = w; }
+      for (uint32_t i = (dlen & ~15u) + lane; i < dlen; i += 64) dst[i] = src[i];
+      if (dlen >= 4) { __builtin_memcpy(&first4, src, 4); }
+    }
+  } else if (codec == PQ_CODEC_SNAPPY_INDEX) {
+    failed = snappy_stream<SN_INDEX>(src, slen, dst, dlen, true, job.index, aligned, first4, s_ring, s_win, lane);
+    if (job.flags & PQ_JOB_FORCE_FALLBACK) aligned = false;
+    if (lane == 0) {
+      if (failed || !aligned) job.index[0] = 1u;                      // the page is inflated by its FINISH job
+      else job.index[1 + (dlen + 65535u) / 65536u] = slen;           // (the end of the last block)
+    }
+    if (failed && lane == 0) codec_error(job.err);
+    return;
+  } else if (codec == PQ_CODEC_SNAPPY || codec == PQ_CODEC_SNAPPY_BLOCK || codec == PQ_CODEC_SNAPPY_FINISH) {
+    bool run = true, preamble = true;
+    if (codec != PQ_CODEC_SNAPPY) {
+      const uint32_t given_up = __hip_atomic_load(job.index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (codec == PQ_CODEC_SNAPPY_BLOCK) {
+        if (given_up) return;
+        const uint32_t k = job.block;
+        const uint32_t s0 = job.index[1 + k], s1 = job.index[2 + k];
+        if (s0 > s1 || s1 > slen || (uint64_t)k * 65536u >= dlen) { if (lane == 0) __hip_atomic_store(job.index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        src += s0; slen = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s1 - s0));
+        dst += (size_t)k * 65536u; dlen = dlen - k * 65536u < 65536u ? dlen - k * 65536u : 65536u;
+        preamble = false;
+      } else if (!given_up) {                   // every block was inflated by its own wave: only the page descriptor is left
+        run = false;
+        if (dlen >= 4) first4 = __hip_atomic_load((const uint32_t*)dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (run) failed = snappy_stream<SN_FULL>(src, slen, dst, dlen, preamble, nullptr, aligned, first4, s_ring, s_win, lane);
+    if (codec == PQ_CODEC_SNAPPY_BLOCK) {       // (an offset that reaches below the block is not damage: the page is redone whole)
+      if (failed && lane == 0) __hip_atomic_store(job.index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
   } else {
     failed = true;
   }

@@ -42,8 +42,13 @@ struct PqDecodeParams {
 // ---- page decompression (parquet_codec.hip) ---------------------------------------------------------------------------
 // A compressed chunk is inflated page by page into an uncompressed image of the chunk; the page descriptors point into that
 // image.  One job = one byte range of the raw chunk -> its place in the image.
-enum : uint32_t { PQ_CODEC_STORED = 0, PQ_CODEC_SNAPPY = 1 };
-enum : uint32_t { PQ_JOB_KEEP_LEVELS = 1 };   // with `page`: the column's definition levels are decoded (else only skipped)
+enum : uint32_t { PQ_CODEC_STORED = 0, PQ_CODEC_SNAPPY = 1,
+                  // a snappy page of several 64 KiB blocks, inflated block by block (parquet_codec.hip): three jobs in three launches
+                  PQ_CODEC_SNAPPY_INDEX = 2,    // walks the element chain, writes where every block starts in the input
+                  PQ_CODEC_SNAPPY_BLOCK = 3,    // inflates block `block` (one per block of the page)
+                  PQ_CODEC_SNAPPY_FINISH = 4 }; // patches the page descriptor; inflates the whole page if the blocks gave up
+enum : uint32_t { PQ_JOB_KEEP_LEVELS = 1,       // with `page`: the column's definition levels are decoded (else only skipped)
+                  PQ_JOB_FORCE_FALLBACK = 2 };  // INDEX job: report "not block-aligned" (tests of the FINISH path)
 struct PqCodecJob {
   const uint8_t* raw;         // the chunk as it lies in the file (in HBM)
   uint8_t* image;             // the chunk's uncompressed image
@@ -55,7 +60,9 @@ struct PqCodecJob {
   int32_t page;               // >= 0: a V1 data page of an optional column -- [4-byte length][levels][values] can only be told
                               // apart after inflation: the kernel fills levels_at / levels_len / values_at / values_len of pages[page]
   uint32_t flags;             // PQ_JOB_*
-  uint32_t pad;
+  uint32_t block;             // SNAPPY_BLOCK: which 64 KiB block of the page
+  uint32_t* index;            // SNAPPY_INDEX / _BLOCK / _FINISH: [0] != 0: the blocks gave up; [1 + k]: input position of block k;
+                              // [1 + blocks]: the page's compressed length (zero-filled before the launches)
 };
 // One launch serves every compressed page of every column and row group of a call's wave (jobs carry their own buffers):
 // a page is a serial chain, so the pages in flight are the parallelism -- per-column launches on the columns' streams left the

@@ -479,17 +479,49 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
     fork_streams(ctx);
     WaveLaunch wave;
     for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j, sel, wave);
-    BufferPtr jobs_dev;
+    BufferPtr jobs_dev, index_dev;
     hipEvent_t ev_inflated = nullptr;
     if (!wave.jobs.empty()) {   // ONE inflate launch for every compressed page of the wave, behind the last upload
       const hipStream_t ustream = ctx.aux[Context::kCopyStream];
-      auto keep = std::make_shared<std::vector<PqCodecJob>>(std::move(wave.jobs));
+      // A snappy page of several 64 KiB blocks is inflated block by block (parquet_codec.hip): an INDEX job walks its element
+      // chain and notes where each block starts, one BLOCK job per block moves the bytes, a FINISH job patches the page
+      // descriptor (and redoes the page with one wave in the case the format allows and no compressor produces: blocks that
+      // depend on each other).  Three launches of the one kernel, in stream order.
+      auto keep = std::make_shared<std::vector<PqCodecJob>>();
+      std::vector<PqCodecJob> blocks, finish;
+      size_t index_words = 0;
+      for (const PqCodecJob& j : wave.jobs) {
+        if (ctx.opt_snappy_blocks == 0 || j.codec != PQ_CODEC_SNAPPY || j.dst_len < 3u * 65536u) { blocks.push_back(j); continue; }
+        const uint32_t nblk = (j.dst_len + 65535u) / 65536u;
+        PqCodecJob a = j;
+        a.index = (uint32_t*)(uintptr_t)(index_words * sizeof(uint32_t));   // (relative until the table is allocated below)
+        PqCodecJob c = a; c.codec = PQ_CODEC_SNAPPY_FINISH;
+        finish.push_back(c);
+        a.page = -1; a.flags = ctx.opt_snappy_blocks == 2 ? PQ_JOB_FORCE_FALLBACK : 0u;
+        a.codec = PQ_CODEC_SNAPPY_BLOCK;
+        for (uint32_t k = 0; k < nblk; ++k) { a.block = k; blocks.push_back(a); }
+        a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
+        keep->push_back(a);
+        index_words += nblk + 2;
+      }
+      const size_t n_index = keep->size(), n_blocks = blocks.size(), n_finish = finish.size();
+      keep->insert(keep->end(), blocks.begin(), blocks.end());
+      keep->insert(keep->end(), finish.begin(), finish.end());
+      if (index_words) {
+        index_dev = make_device_buffer(index_words * sizeof(uint32_t) + 16, ctx.device);
+        check_hip(hipMemsetAsync(index_dev->ptr, 0, index_words * sizeof(uint32_t), ustream), "memset");
+        for (PqCodecJob& j : *keep) if (j.codec >= PQ_CODEC_SNAPPY_INDEX) j.index = (uint32_t*)((uint8_t*)index_dev->ptr + (uintptr_t)j.index);
+      }
       jobs_dev = make_device_buffer(keep->size() * sizeof(PqCodecJob) + 16, ctx.device);
       check_hip(hipMemcpyAsync(jobs_dev->ptr, keep->data(), keep->size() * sizeof(PqCodecJob), hipMemcpyHostToDevice, ustream), "upload inflate jobs");
       jobs.front().work.front().host_keep.push_back(keep);
-      PqCodecParams cp{};
-      cp.jobs = (const PqCodecJob*)jobs_dev->ptr; cp.n_jobs = (int32_t)keep->size();
-      check_hip(pq_launch_inflate(cp, ustream), "launch pq_inflate_kernel");
+      const PqCodecJob* at = (const PqCodecJob*)jobs_dev->ptr;
+      for (const size_t n : {n_index, n_blocks, n_finish}) {
+        PqCodecParams cp{};
+        cp.jobs = at; cp.n_jobs = (int32_t)n;
+        check_hip(pq_launch_inflate(cp, ustream), "launch pq_inflate_kernel");
+        at += n;
+      }
       ev_inflated = upload_event(ctx, wave.n_events++);
       check_hip(hipEventRecord(ev_inflated, ustream), "hipEventRecord(inflate)");
     }

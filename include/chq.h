@@ -95,7 +95,10 @@ void* chq_ctx_stream(const chq_ctx* ctx);
  * one-launch path), "stash" (-1 auto .. 2 predicate columns kept in LDS between the two phases), "split_rows" (rows from
  * which a batch is launched as complete tiles + tail), "uniform_utf8_rows" (batches of at least this many rows -- default 2^24, 0 = never -- have
  * their Utf8 columns checked for ONE value length and, if so, filtered as fixed-width columns), "parquet_page_rows" (chq_record_to_parquet: rows per data page,
- * default 65 536, rounded to multiples of 4 096; a chunk never gets more than 64 pages).  Unknown keys fail.
+ * default 65 536, rounded to multiples of 4 096; a chunk never gets more than 64 pages), "snappy_blocks" (Parquet scan: 1 = a
+ * snappy page of three or more 64 KiB blocks is inflated one wave per BLOCK after a walk of its element chain, 0 = one wave
+ * per page, 2 = the blocks give up and the page is redone whole -- the path a stream with blocks that depend on each other
+ * takes; for tests).  Unknown keys fail.
  *
  * Type coverage of expressions = the reference's (RU/compute_value.rs:350-431): the integer / float coercion table,
  * Utf8 and Boolean comparisons, Float16 (widening, f16 arithmetic and comparisons), same-type comparisons of Date32 /

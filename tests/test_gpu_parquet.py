@@ -243,8 +243,20 @@ def test_snappy_elements_the_batched_parser_must_order(ctx):
     assert len(elements) > 40_000
     values = np.frombuffer(stream, dtype=np.int64)
     t = pa.table({"v": pa.array(values)}, schema=pa.schema([pa.field("v", pa.int64(), nullable=False)]))
-    for kw in [dict(data_page_size=1 << 26), dict(data_page_size=1 << 20), dict(data_page_size=70_000), dict(data_page_version="2.0", data_page_size=1 << 26)]:
-        check(write_bytes(t, compression="snappy", use_dictionary=False, **kw), ctx)
+    files = [write_bytes(t, compression="snappy", use_dictionary=False, **kw)
+             for kw in [dict(data_page_size=1 << 26), dict(data_page_size=1 << 20), dict(data_page_size=70_000), dict(data_page_version="2.0", data_page_size=1 << 26)]]
+    for raw in files:
+        check(raw, ctx)
+    # pages of three and more 64 KiB blocks were inflated one wave per block (option snappy_blocks, default 1); the same files
+    # with one wave per page (0), and with the blocks giving up so that the FINISH job redoes the page (2)
+    for mode in (0, 2):
+        c = chq.Context(0)
+        c.set_option("snappy_blocks", mode)
+        for raw in files[:2]:
+            check(raw, c)
+        opt = pa.table({"v": pa.array(values[:300_000], mask=rng.random(300_000) < 0.3)})    # V1 optional: the descriptor patch
+        check(write_bytes(opt, compression="snappy", use_dictionary=False, data_page_size=1 << 22), c)
+        c.close()
 
 
 def test_damaged_snappy_pages_are_reported(ctx):
