@@ -85,7 +85,14 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
     const uint32_t n = slen - wlo < SN_WIN ? slen - wlo : SN_WIN;
     const uint32_t skew = (uint32_t)((uintptr_t)(src + wlo) & 3);
     const uint32_t* g = (const uint32_t*)(src + wlo - skew);   // aligned dword loads (the raw buffer is padded by 64 bytes)
-    for (uint32_t i = lane; i < (n + skew + 3) / 4 + 2; i += 64) ((uint32_t*)s_win)[i] = g[i];
+    // (all of a lane's loads are issued before the first is waited for: as a loop of load - wait - store this was seventeen
+    // HBM round trips per window, ~40 us, and the largest cost per input byte)
+    const uint32_t cnt = (n + skew + 3) / 4 + 2;                 // at most SN_WIN / 4 + 3 dwords
+    uint32_t t[SN_WIN / 256 + 1];
+#pragma unroll
+    for (uint32_t k = 0; k < SN_WIN / 256 + 1; ++k) { const uint32_t i = k * 64 + lane; t[k] = i < cnt ? g[i] : 0u; }
+#pragma unroll
+    for (uint32_t k = 0; k < SN_WIN / 256 + 1; ++k) { const uint32_t i = k * 64 + lane; if (i < cnt) ((uint32_t*)s_win)[i] = t[k]; }
     wend = wlo + n;
     wbias = wlo - skew;                     // (may wrap below zero: only ever used in `pos - wbias`)
     __builtin_amdgcn_wave_barrier();        // one wave: its LDS accesses execute in order, the compiler must keep them so
@@ -130,24 +137,16 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
       b14 = (uint32_t)(hv >> 8);              // b1 | b2 << 8 | b3 << 16 | b4 << 24
     }
     const uint32_t kind = tag & 3u;
-    uint32_t len, off = 0, hdr;
-    bool bad = false;                         // this header cannot be an element (only matters if the chain lands on it)
-    if (kind == 0) {
-      len = tag >> 2; hdr = 1;
-      if (len >= 60) {
-        const uint32_t nb = len - 59;
-        len = nb == 4 ? b14 : (b14 & ((1u << (8 * nb)) - 1u));
-        hdr = 1 + nb;
-      }
-      bad = len == 0xffffffffu || p + hdr > slen;
-      len += 1;
-      if (!bad) bad = len > slen - p - hdr;
-    } else {
-      if (kind == 1) { len = ((tag >> 2) & 7u) + 4; off = ((tag >> 5) << 8) | (b14 & 0xffu); hdr = 2; }
-      else if (kind == 2) { len = (tag >> 2) + 1; off = b14 & 0xffffu; hdr = 3; }
-      else { len = (tag >> 2) + 1; off = b14; hdr = 5; }
-      bad = p + hdr > slen;
-    }
+    // (selects, not branches: all 64 lanes decode a header, whatever its kind)
+    const uint32_t t6 = tag >> 2;
+    const uint32_t nb = kind == 0 && t6 >= 60 ? t6 - 59 : 0u;                      // literal: bytes of extended length
+    const uint32_t ext = nb == 4 ? b14 : (b14 & ((1u << (8 * nb)) - 1u));
+    const uint32_t len0 = nb ? ext : (kind == 1 ? (t6 & 7u) + 3 : t6);            // length - 1
+    const uint32_t hdr = kind == 0 ? 1 + nb : (kind == 1 ? 2u : (kind == 2 ? 3u : 5u));
+    const uint32_t off = kind == 0 ? 0u : (kind == 1 ? ((tag >> 5) << 8) | (b14 & 0xffu) : (kind == 2 ? (b14 & 0xffffu) : b14));
+    const uint32_t len = len0 + 1;
+    // this header cannot be an element (only matters if the chain lands on it): it, or a literal's bytes, pass the input's end
+    const bool bad = p + hdr > slen || (kind == 0 && (len0 == 0xffffffffu || len > slen - p - hdr));
     const uint32_t adv = kind != 0 ? hdr : (bad || len > 64 ? 4096u : hdr + len);   // input bytes to the next element
     // ---- the chain (scalar): element starts M; the batch ends at input byte `cur` ----
     const uint32_t lim = slen - pos < 64 ? slen - pos : 64;
@@ -244,16 +243,17 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
           const bool ready = ((un >> lane) & 1ull) && src_end <= F;  // (the first unfinished copy always is)
           un &= ~__builtin_amdgcn_ballot_w64(ready);
           uint32_t r = 0;                                            // i mod off, kept incrementally
-          for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(ready && j < len); j += 8) {
-            uint8_t v[8];
+          // four bytes per lane and pass (most copies are 4 to 8 bytes long).  The reads are not predicated: any
+          // address inside the ring may be read, and a lane that is not ready simply drops what it got
+          for (uint32_t j = 0; __builtin_amdgcn_ballot_w64(ready && j < len); j += 4) {
+            uint8_t v[4];
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u) {
-              v[u] = 0;
-              if (ready && j + u < len) v[u] = s_ring[(src0 + r) & SN_MASK];
+            for (uint32_t u = 0; u < 4; ++u) {
+              v[u] = s_ring[(src0 + r) & SN_MASK];
               r = r + 1 == off ? 0 : r + 1;
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 8; ++u)
+            for (uint32_t u = 0; u < 4; ++u)
               if (ready && j + u < len) s_ring[(opos + j + u) & SN_MASK] = v[u];
           }
         }

@@ -259,6 +259,50 @@ def test_snappy_elements_the_batched_parser_must_order(ctx):
         c.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_snappy_random_element_mixes(ctx, seed):
+    """seeded streams of literals, repeats at any distance up to beyond the ring, runs of short periods and incompressible
+    stretches, in Int64 / Int32 / Float64 / Utf8 columns with and without nulls, page sizes from a few KB to one page"""
+    rng = np.random.default_rng(seed)
+    def rnd(k):
+        return rng.integers(0, 256, k, dtype=np.uint8).tobytes()
+    mix = bytearray(rnd(64))
+    short = int(rng.integers(3, 9))               # how literal-heavy this stream is
+    while len(mix) < 700_000:
+        c = rng.integers(0, 10)
+        if c < short:
+            mix += rnd(int(rng.integers(1, 1 << int(rng.integers(1, 8)))))
+        elif c < 9:
+            back = int(rng.integers(1, min(len(mix), 66000)))
+            k = int(rng.integers(4, 1 << int(rng.integers(3, 9))))
+            at = len(mix) - back
+            for _ in range(k // max(back, 1) + 1):      # (a repeat longer than its distance overlaps itself)
+                mix += mix[at:at + min(k, back)]
+        else:
+            mix += rnd(int(rng.integers(1, 12))) * int(rng.integers(2, 200))
+    stream = bytes(mix[:len(mix) // 8 * 8])
+    i64 = np.frombuffer(stream, dtype=np.int64)
+    n = len(i64)
+    text = (np.frombuffer(stream, dtype=np.uint8) % 26 + 97).astype(np.uint8).tobytes() * 2      # 16 bytes per row: enough
+    lens = rng.integers(0, 11, n)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    t = pa.table({
+        "a": pa.array(i64),
+        "b": pa.array(np.frombuffer(stream, dtype=np.int32)[:n], mask=rng.random(n) < 0.2),
+        "c": pa.array(np.frombuffer(stream, dtype=np.float64).view(np.int64)[:n] % 1000 / 8.0),
+        "s": pa.Array.from_buffers(pa.utf8(), n, [None, pa.py_buffer(offs.tobytes()), pa.py_buffer(text[:int(offs[-1])])]),
+    })
+    page = int(rng.choice([4096, 70_000, 1 << 18, 1 << 20, 1 << 26]))
+    kw = dict(use_dictionary=bool(rng.integers(0, 2)), data_page_size=page, data_page_version=str(rng.choice(["1.0", "2.0"])),
+              row_group_size=int(rng.choice([n, n // 3 + 1])))
+    raw = write_bytes(t, compression="snappy", **kw)
+    check(raw, ctx)
+    c = chq.Context(0)
+    c.set_option("snappy_blocks", int(seed % 3))
+    check(raw, c)
+    c.close()
+
+
 def test_damaged_snappy_pages_are_reported(ctx):
     """compressed bytes overwritten: offsets beyond the output so far, literals running past the page, a wrong uncompressed
     length -- the inflate kernel bounds every element and the call names the column"""
