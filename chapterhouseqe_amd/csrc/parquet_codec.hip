@@ -273,6 +273,24 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
 
 }  // namespace
 
+// The INDEX jobs of a launch (one wave each): only the 4 KiB input window in LDS, so these waves do not compete with the
+// BLOCK jobs of other pages for the CUs' LDS (two 64 KiB rings fill a CU).
+__global__ __launch_bounds__(64) void pq_inflate_index_kernel(const PqCodecParams p) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[SN_WIN + 32];
+  const int lane = threadIdx.x;
+  const PqCodecJob job = p.jobs[blockIdx.x];
+  const uint32_t slen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.src_len), dlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.dst_len);
+  bool aligned = true;
+  uint32_t first4 = 0;
+  const bool failed = snappy_stream<SN_INDEX>(job.raw + job.src_at, slen, nullptr, dlen, true, job.index, aligned, first4, nullptr, s_win, lane);
+  if (job.flags & PQ_JOB_FORCE_FALLBACK) aligned = false;
+  if (lane == 0) {
+    if (failed || !aligned) job.index[0] = 1u;                        // the page is inflated by its FINISH job
+    else job.index[1 + (dlen + 65535u) / 65536u] = slen;             // (the end of the last block)
+    if (failed) codec_error(job.err);
+  }
+}
+
 // One wave per job.  job.raw: the chunk as it lies in the file; job.image: the uncompressed image (both padded by 64 bytes).
 __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[SN_RING];
@@ -293,15 +311,6 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
       for (uint32_t i = (dlen & ~15u) + lane; i < dlen; i += 64) dst[i] = src[i];
       if (dlen >= 4) { __builtin_memcpy(&first4, src, 4); }
     }
-  } else if (codec == PQ_CODEC_SNAPPY_INDEX) {
-    failed = snappy_stream<SN_INDEX>(src, slen, dst, dlen, true, job.index, aligned, first4, s_ring, s_win, lane);
-    if (job.flags & PQ_JOB_FORCE_FALLBACK) aligned = false;
-    if (lane == 0) {
-      if (failed || !aligned) job.index[0] = 1u;                      // the page is inflated by its FINISH job
-      else job.index[1 + (dlen + 65535u) / 65536u] = slen;           // (the end of the last block)
-    }
-    if (failed && lane == 0) codec_error(job.err);
-    return;
   } else if (codec == PQ_CODEC_SNAPPY || codec == PQ_CODEC_SNAPPY_BLOCK || codec == PQ_CODEC_SNAPPY_FINISH) {
     bool run = true, preamble = true;
     if (codec != PQ_CODEC_SNAPPY) {
@@ -344,6 +353,12 @@ __global__ __launch_bounds__(64) void pq_inflate_kernel(const PqCodecParams p) {
 hipError_t pq_launch_inflate(const PqCodecParams& p, hipStream_t s) {
   if (p.n_jobs <= 0) return hipSuccess;
   hipLaunchKernelGGL(pq_inflate_kernel, dim3(p.n_jobs), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t pq_launch_inflate_index(const PqCodecParams& p, hipStream_t s) {
+  if (p.n_jobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pq_inflate_index_kernel, dim3(p.n_jobs), dim3(64), 0, s, p);
   return hipGetLastError();
 }
 

@@ -72,7 +72,8 @@ struct PqCodecParams {
   int32_t n_jobs;
   int32_t pad;
 };
-hipError_t pq_launch_inflate(const PqCodecParams& p, hipStream_t s);
+hipError_t pq_launch_inflate(const PqCodecParams& p, hipStream_t s);         // STORED / SNAPPY / SNAPPY_BLOCK / SNAPPY_FINISH jobs
+hipError_t pq_launch_inflate_index(const PqCodecParams& p, hipStream_t s);   // SNAPPY_INDEX jobs
 
 struct PqRowParams {
   int64_t n_rows;

@@ -487,26 +487,31 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       // chain and notes where each block starts, one BLOCK job per block moves the bytes, a FINISH job patches the page
       // descriptor (and redoes the page with one wave in the case the format allows and no compressor produces: blocks that
       // depend on each other).  Three launches of the one kernel, in stream order.
+      // The INDEX walk is serial per page and its time grows with the page's compressed size, so a few large pages (a 1 MiB
+      // dictionary page of short strings: 11 ms) would hold back the BLOCK launch of all the others: pages of 512 KiB and more
+      // of compressed bytes form a second chain of three launches on a kernel stream, next to the chain of the rest.
       auto keep = std::make_shared<std::vector<PqCodecJob>>();
-      std::vector<PqCodecJob> blocks, finish;
-      size_t index_words = 0;
+      struct Chain { std::vector<PqCodecJob> index, blocks, finish; } chains[2];
+      size_t index_words = 0, n_big = 0, n_indexed = 0;
+      auto indexed = [&](const PqCodecJob& j) { return ctx.opt_snappy_blocks != 0 && j.codec == PQ_CODEC_SNAPPY && j.dst_len >= 3u * 65536u; };
+      for (const PqCodecJob& j : wave.jobs) if (indexed(j)) { ++n_indexed; n_big += j.src_len >= (512u << 10); }
+      const bool two_chains = n_big > 0 && n_big < n_indexed;
       for (const PqCodecJob& j : wave.jobs) {
-        if (ctx.opt_snappy_blocks == 0 || j.codec != PQ_CODEC_SNAPPY || j.dst_len < 3u * 65536u) { blocks.push_back(j); continue; }
+        if (!indexed(j)) { chains[0].blocks.push_back(j); continue; }
+        Chain& ch = chains[two_chains && j.src_len >= (512u << 10) ? 1 : 0];
         const uint32_t nblk = (j.dst_len + 65535u) / 65536u;
         PqCodecJob a = j;
         a.index = (uint32_t*)(uintptr_t)(index_words * sizeof(uint32_t));   // (relative until the table is allocated below)
         PqCodecJob c = a; c.codec = PQ_CODEC_SNAPPY_FINISH;
-        finish.push_back(c);
+        ch.finish.push_back(c);
         a.page = -1; a.flags = ctx.opt_snappy_blocks == 2 ? PQ_JOB_FORCE_FALLBACK : 0u;
         a.codec = PQ_CODEC_SNAPPY_BLOCK;
-        for (uint32_t k = 0; k < nblk; ++k) { a.block = k; blocks.push_back(a); }
+        for (uint32_t k = 0; k < nblk; ++k) { a.block = k; ch.blocks.push_back(a); }
         a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
-        keep->push_back(a);
+        ch.index.push_back(a);
         index_words += nblk + 2;
       }
-      const size_t n_index = keep->size(), n_blocks = blocks.size(), n_finish = finish.size();
-      keep->insert(keep->end(), blocks.begin(), blocks.end());
-      keep->insert(keep->end(), finish.begin(), finish.end());
+      for (const Chain& ch : chains) for (const std::vector<PqCodecJob>* v : {&ch.index, &ch.blocks, &ch.finish}) keep->insert(keep->end(), v->begin(), v->end());
       if (index_words) {
         index_dev = make_device_buffer(index_words * sizeof(uint32_t) + 16, ctx.device);
         check_hip(hipMemsetAsync(index_dev->ptr, 0, index_words * sizeof(uint32_t), ustream), "memset");
@@ -516,12 +521,32 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       check_hip(hipMemcpyAsync(jobs_dev->ptr, keep->data(), keep->size() * sizeof(PqCodecJob), hipMemcpyHostToDevice, ustream), "upload inflate jobs");
       jobs.front().work.front().host_keep.push_back(keep);
       const PqCodecJob* at = (const PqCodecJob*)jobs_dev->ptr;
-      for (const size_t n : {n_index, n_blocks, n_finish}) {
-        PqCodecParams cp{};
-        cp.jobs = at; cp.n_jobs = (int32_t)n;
-        check_hip(pq_launch_inflate(cp, ustream), "launch pq_inflate_kernel");
-        at += n;
+      hipEvent_t ev_big = nullptr, ev_ready = nullptr;
+      if (two_chains) {   // the second chain starts behind everything uploaded so far: the pages, the job list, the cleared index table
+        ev_ready = upload_event(ctx, wave.n_events++);
+        check_hip(hipEventRecord(ev_ready, ustream), "hipEventRecord(jobs)");
       }
+      for (int c = 0; c < 2; ++c) {
+        const Chain& ch = chains[c];
+        if (ch.index.empty() && ch.blocks.empty()) continue;
+        hipStream_t st = ustream;
+        if (c == 1) {
+          st = ctx.aux[0];
+          check_hip(hipStreamWaitEvent(st, ev_ready, 0), "hipStreamWaitEvent(jobs)");
+        }
+        const size_t counts[3] = {ch.index.size(), ch.blocks.size(), ch.finish.size()};
+        for (int k = 0; k < 3; ++k) {
+          PqCodecParams cp{};
+          cp.jobs = at; cp.n_jobs = (int32_t)counts[k];
+          check_hip(k == 0 ? pq_launch_inflate_index(cp, st) : pq_launch_inflate(cp, st), "launch pq_inflate_kernel");
+          at += counts[k];
+        }
+        if (c == 1) {
+          ev_big = upload_event(ctx, wave.n_events++);
+          check_hip(hipEventRecord(ev_big, st), "hipEventRecord(inflate)");
+        }
+      }
+      if (ev_big) check_hip(hipStreamWaitEvent(ustream, ev_big, 0), "hipStreamWaitEvent(inflate)");
       ev_inflated = upload_event(ctx, wave.n_events++);
       check_hip(hipEventRecord(ev_inflated, ustream), "hipEventRecord(inflate)");
     }
