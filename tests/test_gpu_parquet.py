@@ -328,6 +328,36 @@ def test_damaged_snappy_pages_are_reported(ctx):
     assert reported >= 3
 
 
+def test_damaged_snappy_pages_of_several_blocks(ctx):
+    """the same for pages that are inflated block by block: damage in the element headers is found by the index walk (no
+    block job runs), damage in an offset by a block job (the page is redone whole and judged there), damage in literal
+    bytes decodes; a damaged page never keeps a later read from working"""
+    n = 300_000
+    rng = np.random.default_rng(6)
+    t = pa.table({"k": pa.array((np.arange(n) // 3).astype(np.int64)), "s": pa.array(["row %06d of many" % (v % 5000) for v in range(n)])})
+    raw = write_bytes(t, compression="snappy", use_dictionary=False, data_page_size=1 << 20)
+    md = pq.ParquetFile(io.BytesIO(raw)).metadata
+    reported = 0
+    for col in range(2):
+        cm = md.row_group(0).column(col)
+        assert cm.total_uncompressed_size > 6 * 65536
+        for frac in (0.01, 0.2, 0.45, 0.7, 0.97):
+            for width in (1, 3, 64):
+                bad = bytearray(raw)
+                at = cm.data_page_offset + 64 + int((cm.total_compressed_size - 200) * frac)
+                bad[at:at + width] = bytes(rng.integers(0, 256, width, dtype=np.uint8))
+                try:
+                    f = chq.ParquetFile(bytes(bad))
+                    got = f.read_row_group(0, ctx=ctx)
+                    assert got.num_rows == n
+                    got.release()
+                except chq.ChqError as e:
+                    assert e.code in (22, 30), str(e)
+                    reported += 1
+    assert reported >= 5
+    check(raw, ctx)
+
+
 def test_host_result_and_required_columns(ctx):
     n = 5000
     rng = np.random.default_rng(9)
