@@ -11,12 +11,16 @@
 //   tag & 3 == 2  copy, 2-byte offset: length (tag >> 2) + 1, offset = next two bytes (little endian)
 //   tag & 3 == 3  copy, 4-byte offset: length (tag >> 2) + 1, offset = next four bytes
 // An element's position depends on every element before it and a copy may read what the previous element wrote, so a page is
-// a serial chain; pages are independent.  One wavefront per page:
-//   * the last 64 KiB of OUTPUT live in an LDS ring (snappy compressors match inside 64 KiB blocks, so copy offsets stay
-//     below it; larger offsets -- legal, never produced -- read back from HBM): a copy is an LDS read + an LDS write, both
-//     ~64 cycles, instead of a dependent HBM round trip per element;
-//   * the tags are parsed from an LDS window of the INPUT by all 64 lanes at once (uniform control flow, broadcast reads);
-//   * literals stream HBM -> ring with eight loads per lane in flight; the ring is written back to HBM 16 bytes per lane.
+// a serial chain; pages are independent.  The parallelism around that chain (details at snappy_stream below):
+//   * lanes: the chain is parsed 64 INPUT bytes at a time -- every lane decodes the header that would start at its byte, the
+//     scalar unit follows the chain through them with readlane, a batch's literals and copies are moved together;
+//   * waves: a page of three or more 64 KiB blocks of output is walked once without moving bytes (INDEX job) to find where
+//     each block starts in the input, then inflated one wave per block (BLOCK jobs); a FINISH job patches the page
+//     descriptor and redoes the page in the (never produced) case that its blocks depend on each other;
+//   * the last 64 KiB of OUTPUT live in an LDS ring (the format's maximum offset within a compressor's block; larger
+//     offsets -- legal, never produced -- read back from HBM): a copy is an LDS read + an LDS write instead of a dependent
+//     HBM round trip per element; the ring is written back to HBM 16 bytes per lane;
+//   * the input is staged through a 4 KiB LDS window; long literals stream HBM -> ring with eight loads per lane in flight.
 // Memory-bound byte work: no MFMA.  Rates: DESIGN.md section 3.5.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -64,9 +64,10 @@ struct PqCodecJob {
   uint32_t* index;            // SNAPPY_INDEX / _BLOCK / _FINISH: [0] != 0: the blocks gave up; [1 + k]: input position of block k;
                               // [1 + blocks]: the page's compressed length (zero-filled before the launches)
 };
-// One launch serves every compressed page of every column and row group of a call's wave (jobs carry their own buffers):
-// a page is a serial chain, so the pages in flight are the parallelism -- per-column launches on the columns' streams left the
-// twenty slowest pages of a twenty-row-group file sharing the handful of hardware queues the streams map to.
+// A launch serves every compressed page of every column and row group of a call's wave (jobs carry their own buffers):
+// a page is a serial chain, so the pages (and, after the index walk, their 64 KiB blocks) in flight are the parallelism --
+// per-column launches on the columns' streams left the twenty slowest pages of a twenty-row-group file sharing the handful of
+// hardware queues the streams map to.  Launch order on a stream: INDEX jobs, then BLOCK + whole-page jobs, then FINISH jobs.
 struct PqCodecParams {
   const PqCodecJob* jobs;
   int32_t n_jobs;
