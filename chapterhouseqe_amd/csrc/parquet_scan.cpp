@@ -478,80 +478,90 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
     }
     fork_streams(ctx);
     WaveLaunch wave;
-    for (size_t j = 0; j < jobs.size(); ++j) phase_a(ctx, f, next + (int)j, jobs[j], j, sel, wave);
-    BufferPtr jobs_dev, index_dev;
-    hipEvent_t ev_inflated = nullptr;
-    if (!wave.jobs.empty()) {   // ONE inflate launch for every compressed page of the wave, behind the last upload
-      const hipStream_t ustream = ctx.aux[Context::kCopyStream];
-      // A snappy page of several 64 KiB blocks is inflated block by block (parquet_codec.hip): an INDEX job walks its element
-      // chain and notes where each block starts, one BLOCK job per block moves the bytes, a FINISH job patches the page
-      // descriptor (and redoes the page with one wave in the case the format allows and no compressor produces: blocks that
-      // depend on each other).  Three launches of the one kernel, in stream order.
-      // The INDEX walk is serial per page and its time grows with the page's compressed size, so a few large pages (a 1 MiB
-      // dictionary page of short strings: 11 ms) would hold back the BLOCK launch of all the others: pages of 512 KiB and more
-      // of compressed bytes form a second chain of three launches on a kernel stream, next to the chain of the rest.
+    // The compressed pages of the wave are inflated in up to three PARTS of consecutive row groups, each behind the uploads
+    // of its own row groups (the GPU would otherwise idle until the wave's last upload); the decode closures of a part's
+    // columns wait for that part's event.
+    //   A snappy page of several 64 KiB blocks is inflated block by block (parquet_codec.hip): an INDEX job walks its element
+    // chain and notes where each block starts, one BLOCK job per block moves the bytes, a FINISH job patches the page
+    // descriptor (and redoes the page with one wave in the case the format allows and no compressor produces: blocks that
+    // depend on each other): a CHAIN of three launches in stream order.
+    //   The INDEX walk is serial per page and its time grows with the page's compressed size, so a few large pages (a 1 MiB
+    // dictionary page of short strings: 13 ms) would hold back the BLOCK launch of all the others: pages of 512 KiB and more
+    // of compressed bytes are collected over the whole wave and form ONE more chain on a stream of its own, behind the last
+    // upload.  (Their walks all have to run side by side -- in one launch: a chain per part put them behind each other on
+    // the few hardware queues the streams share, 33 -> 51 ms for the 20-row-group sample.)
+    struct Chain { std::vector<PqCodecJob> index, blocks, finish; };
+    std::vector<std::shared_ptr<void>> host_keep;
+    std::vector<BufferPtr> device_keep;
+    std::vector<hipEvent_t> col_inflated;      // per entry of wave.cols
+    const hipStream_t ustream = ctx.aux[Context::kCopyStream];
+    auto launch_chain = [&](const Chain& ch, hipStream_t st) -> hipEvent_t {
       auto keep = std::make_shared<std::vector<PqCodecJob>>();
-      struct Chain { std::vector<PqCodecJob> index, blocks, finish; } chains[2];
-      size_t index_words = 0, n_big = 0, n_indexed = 0;
-      auto indexed = [&](const PqCodecJob& j) { return ctx.opt_snappy_blocks != 0 && j.codec == PQ_CODEC_SNAPPY && j.dst_len >= 3u * 65536u; };
-      for (const PqCodecJob& j : wave.jobs) if (indexed(j)) { ++n_indexed; n_big += j.src_len >= (512u << 10); }
-      const bool two_chains = n_big > 0 && n_big < n_indexed;
-      for (const PqCodecJob& j : wave.jobs) {
-        if (!indexed(j)) { chains[0].blocks.push_back(j); continue; }
-        Chain& ch = chains[two_chains && j.src_len >= (512u << 10) ? 1 : 0];
-        const uint32_t nblk = (j.dst_len + 65535u) / 65536u;
-        PqCodecJob a = j;
-        a.index = (uint32_t*)(uintptr_t)(index_words * sizeof(uint32_t));   // (relative until the table is allocated below)
-        PqCodecJob c = a; c.codec = PQ_CODEC_SNAPPY_FINISH;
-        ch.finish.push_back(c);
-        a.page = -1; a.flags = ctx.opt_snappy_blocks == 2 ? PQ_JOB_FORCE_FALLBACK : 0u;
-        a.codec = PQ_CODEC_SNAPPY_BLOCK;
-        for (uint32_t k = 0; k < nblk; ++k) { a.block = k; ch.blocks.push_back(a); }
-        a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
-        ch.index.push_back(a);
-        index_words += nblk + 2;
-      }
-      for (const Chain& ch : chains) for (const std::vector<PqCodecJob>* v : {&ch.index, &ch.blocks, &ch.finish}) keep->insert(keep->end(), v->begin(), v->end());
-      if (index_words) {
-        index_dev = make_device_buffer(index_words * sizeof(uint32_t) + 16, ctx.device);
+      for (const std::vector<PqCodecJob>* v : {&ch.index, &ch.blocks, &ch.finish}) keep->insert(keep->end(), v->begin(), v->end());
+      size_t index_words = 0;
+      for (const PqCodecJob& j : ch.index) index_words += (j.dst_len + 65535u) / 65536u + 2;
+      if (index_words) {   // (the jobs carry offsets into the table until it exists)
+        BufferPtr index_dev = make_device_buffer(index_words * sizeof(uint32_t) + 16, ctx.device);
         check_hip(hipMemsetAsync(index_dev->ptr, 0, index_words * sizeof(uint32_t), ustream), "memset");
         for (PqCodecJob& j : *keep) if (j.codec >= PQ_CODEC_SNAPPY_INDEX) j.index = (uint32_t*)((uint8_t*)index_dev->ptr + (uintptr_t)j.index);
+        device_keep.push_back(index_dev);
       }
-      jobs_dev = make_device_buffer(keep->size() * sizeof(PqCodecJob) + 16, ctx.device);
+      BufferPtr jobs_dev = make_device_buffer(keep->size() * sizeof(PqCodecJob) + 16, ctx.device);
       check_hip(hipMemcpyAsync(jobs_dev->ptr, keep->data(), keep->size() * sizeof(PqCodecJob), hipMemcpyHostToDevice, ustream), "upload inflate jobs");
-      jobs.front().work.front().host_keep.push_back(keep);
+      host_keep.push_back(keep); device_keep.push_back(jobs_dev);
+      // the chain starts behind everything uploaded so far: the pages, the job list, the cleared index table
+      const hipEvent_t ev_ready = upload_event(ctx, wave.n_events++);
+      check_hip(hipEventRecord(ev_ready, ustream), "hipEventRecord(jobs)");
+      check_hip(hipStreamWaitEvent(st, ev_ready, 0), "hipStreamWaitEvent(jobs)");
       const PqCodecJob* at = (const PqCodecJob*)jobs_dev->ptr;
-      hipEvent_t ev_big = nullptr, ev_ready = nullptr;
-      if (two_chains) {   // the second chain starts behind everything uploaded so far: the pages, the job list, the cleared index table
-        ev_ready = upload_event(ctx, wave.n_events++);
-        check_hip(hipEventRecord(ev_ready, ustream), "hipEventRecord(jobs)");
+      const size_t counts[3] = {ch.index.size(), ch.blocks.size(), ch.finish.size()};
+      for (int k = 0; k < 3; ++k) {
+        PqCodecParams cp{};
+        cp.jobs = at; cp.n_jobs = (int32_t)counts[k];
+        check_hip(k == 0 ? pq_launch_inflate_index(cp, st) : pq_launch_inflate(cp, st), "launch pq_inflate_kernel");
+        at += counts[k];
       }
-      for (int c = 0; c < 2; ++c) {
-        const Chain& ch = chains[c];
-        if (ch.index.empty() && ch.blocks.empty()) continue;
-        hipStream_t st = ustream;
-        if (c == 1) {
-          st = ctx.aux[0];
-          check_hip(hipStreamWaitEvent(st, ev_ready, 0), "hipStreamWaitEvent(jobs)");
-        }
-        const size_t counts[3] = {ch.index.size(), ch.blocks.size(), ch.finish.size()};
-        for (int k = 0; k < 3; ++k) {
-          PqCodecParams cp{};
-          cp.jobs = at; cp.n_jobs = (int32_t)counts[k];
-          check_hip(k == 0 ? pq_launch_inflate_index(cp, st) : pq_launch_inflate(cp, st), "launch pq_inflate_kernel");
-          at += counts[k];
-        }
-        if (c == 1) {
-          ev_big = upload_event(ctx, wave.n_events++);
-          check_hip(hipEventRecord(ev_big, st), "hipEventRecord(inflate)");
-        }
+      const hipEvent_t ev_done = upload_event(ctx, wave.n_events++);
+      check_hip(hipEventRecord(ev_done, st), "hipEventRecord(inflate)");
+      return ev_done;
+    };
+    auto add_page = [&](Chain& ch, const PqCodecJob& j) {   // an indexed page: its INDEX, BLOCK and FINISH jobs
+      size_t index_words = 0;
+      for (const PqCodecJob& q : ch.index) index_words += (q.dst_len + 65535u) / 65536u + 2;
+      const uint32_t nblk = (j.dst_len + 65535u) / 65536u;
+      PqCodecJob a = j;
+      a.index = (uint32_t*)(uintptr_t)(index_words * sizeof(uint32_t));
+      PqCodecJob c = a; c.codec = PQ_CODEC_SNAPPY_FINISH;
+      ch.finish.push_back(c);
+      a.page = -1; a.flags = ctx.opt_snappy_blocks == 2 ? PQ_JOB_FORCE_FALLBACK : 0u;
+      a.codec = PQ_CODEC_SNAPPY_BLOCK;
+      for (uint32_t k = 0; k < nblk; ++k) { a.block = k; ch.blocks.push_back(a); }
+      a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
+      ch.index.push_back(a);
+    };
+    Chain large;
+    const size_t n_parts = jobs.size() >= 12 ? 3 : (jobs.size() >= 6 ? 2 : 1);
+    size_t job0 = 0, part = 0;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+      phase_a(ctx, f, next + (int)j, jobs[j], j, sel, wave);
+      if ((j + 1) * n_parts / jobs.size() == part) continue;     // (this part goes on)
+      Chain ch;
+      for (size_t q = job0; q < wave.jobs.size(); ++q) {
+        const PqCodecJob& pj = wave.jobs[q];
+        if (ctx.opt_snappy_blocks == 0 || pj.codec != PQ_CODEC_SNAPPY || pj.dst_len < 3u * 65536u) ch.blocks.push_back(pj);
+        else add_page(pj.src_len >= (512u << 10) ? large : ch, pj);
       }
-      if (ev_big) check_hip(hipStreamWaitEvent(ustream, ev_big, 0), "hipStreamWaitEvent(inflate)");
-      ev_inflated = upload_event(ctx, wave.n_events++);
-      check_hip(hipEventRecord(ev_inflated, ustream), "hipEventRecord(inflate)");
+      hipEvent_t ev = nullptr;
+      if (!ch.blocks.empty()) ev = launch_chain(ch, ctx.aux[(part % 2) * 2]);   // (two streams: a part's INDEX launch next to the BLOCK launch before it)
+      col_inflated.resize(wave.cols.size(), ev);
+      job0 = wave.jobs.size(); ++part;
     }
-    for (WaveLaunch::Col& c : wave.cols) {
-      check_hip(hipStreamWaitEvent(c.stream, c.compressed ? ev_inflated : c.uploaded, 0), "hipStreamWaitEvent(upload)");
+    col_inflated.resize(wave.cols.size(), nullptr);
+    const hipEvent_t ev_large = large.index.empty() ? nullptr : launch_chain(large, ctx.aux[1]);
+    for (size_t k = 0; k < wave.cols.size(); ++k) {
+      WaveLaunch::Col& c = wave.cols[k];
+      check_hip(hipStreamWaitEvent(c.stream, c.compressed && col_inflated[k] ? col_inflated[k] : c.uploaded, 0), "hipStreamWaitEvent(upload)");
+      if (c.compressed && ev_large) check_hip(hipStreamWaitEvent(c.stream, ev_large, 0), "hipStreamWaitEvent(inflate)");
       c.launch();
     }
     join_streams(ctx);
