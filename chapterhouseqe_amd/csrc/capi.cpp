@@ -305,7 +305,7 @@ chq_status chq_ctx_set_option(chq_ctx* ctx, const char* key, int64_t value) {
     else if (k == "group_fold") ctx->c.opt_group_fold = value != 0;
     else if (k == "group_bits") ctx->c.opt_group_bits = value != 0;
     else if (k == "uniform_utf8_rows") ctx->c.opt_uniform_utf8_rows = value < 0 ? 0 : value;
-    else if (k == "snappy_blocks") { if (value < 0 || value > 2) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "snappy_blocks is 0, 1 or 2"}; ctx->c.opt_snappy_blocks = value; }
+    else if (k == "snappy_blocks") { if (value < 0 || value > 3) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "snappy_blocks is 0, 1, 2 or 3"}; ctx->c.opt_snappy_blocks = value; }
     else if (k == "parquet_page_rows") { if (value < 1) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "parquet_page_rows must be positive"}; ctx->c.opt_parquet_page_rows = value; }
     else if (k == "large_host") ctx->c.opt_large_host = value != 0;
     else if (k == "large_host_chunk") { if (value < 0) throw ChqError{CHQ_ERR_ARROW_INVALID_ARGUMENT, "large_host_chunk must not be negative"}; ctx->c.opt_large_host_chunk = value; }

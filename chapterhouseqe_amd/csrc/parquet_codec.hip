@@ -60,11 +60,20 @@ enum { SN_FULL = 0, SN_INDEX = 1 };
 //             does not promise it: `aligned` comes back false if an element straddles a boundary, a block job that meets
 //             an offset reaching below its block gives up, and either way the page is then redone by one wave (FINISH).
 // Returns true if the stream is damaged.
+// A part of a stream's element chain (SN_INDEX): the walk begins at input byte `start` with `out0` bytes of output behind it
+// and ends at the first element that starts at or behind `stop`.  `whole`: it must end at the stream's end with dlen bytes of
+// output.  `lead`: the start is a guess (see pq_inflate_index_kernel) -- an element too long for a batch is then taken for a
+// misread, not followed.  Where the walk ended comes back in end_pos / end_out, where the elements begin (behind the
+// preamble) in `first`.
+struct SnappySpan { uint32_t start, stop, out0; bool whole, lead; uint32_t end_pos, end_out, first; };
+
 template <int MODE>
 __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t slen, uint8_t* dst, const uint32_t dlen, const bool preamble,
-                                               uint32_t* index, bool& aligned, uint32_t& first4, uint8_t* s_ring, uint8_t* s_win, const int lane) {
+                                               uint32_t* index, bool& aligned, uint32_t& first4, uint8_t* s_ring, uint8_t* s_win, const int lane,
+                                               SnappySpan* span = nullptr) {
   bool failed = false;
-  uint32_t pos = 0;                           // next input byte
+  const uint32_t stop = span ? span->stop : slen;
+  uint32_t pos = span ? span->start : 0;      // next input byte
   // ---- preamble: the uncompressed length must be what the page header promised ----
   if (preamble) {
     uint32_t v = 0; int sh = 0; bool done = false;
@@ -74,7 +83,8 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
   // (every lane loaded the same bytes: tell the compiler, so that what steers the loops below lives in scalar registers)
   pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
   failed = __builtin_amdgcn_readfirstlane((int)failed) != 0;
-  uint32_t out = 0, flushed = 0;              // bytes produced / bytes already written back (multiple of 16)
+  if (span) span->first = pos;
+  uint32_t out = span ? span->out0 : 0, flushed = 0;   // bytes produced / bytes already written back (multiple of 16)
   uint32_t wlo = 0, wend = 0, wbias = 0;      // input bytes [wlo, wend) are staged: s_win[k] = input byte wbias + k
   bool got4 = false;                          // the first four output bytes were captured (while they are still in the ring)
   auto flush = [&](uint32_t upto) {           // ring [flushed, upto) -> HBM; upto is a multiple of 16 (or the end)
@@ -129,7 +139,7 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
   //      do; a chain of copies that each read the previous one's bytes degrades to one element per round.
   // (The version before this one walked the chain one element at a time: ~1400 cycles of dependent LDS round trips and
   // issue latency per element with one wave per SIMD, 60+ ms for a 1 MB page of short elements.)
-  while (!failed && pos < slen && out < dlen) {
+  while (!failed && pos < stop && out < dlen) {
     if (!(pos >= wlo && (pos + 72 <= wend || wend >= slen))) refill(pos);
     const uint32_t p = pos + lane;            // this lane's input byte
     uint32_t tag = 0, b14 = 0;
@@ -153,7 +163,7 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
     const bool bad = p + hdr > slen || (kind == 0 && (len0 == 0xffffffffu || len > slen - p - hdr));
     const uint32_t adv = kind != 0 ? hdr : (bad || len > 64 ? 4096u : hdr + len);   // input bytes to the next element
     // ---- the chain (scalar): element starts M; the batch ends at input byte `cur` ----
-    const uint32_t lim = slen - pos < 64 ? slen - pos : 64;
+    const uint32_t lim = stop - pos < 64 ? stop - pos : 64;
     // (an element must END inside the slice -- lane + adv <= 63 -- so that `cur` stays a lane number and the loop below
     // has one test per element; a longer literal, or one that reaches the slice's end, starts the next batch)
     const uint64_t fits = __builtin_amdgcn_ballot_w64((uint32_t)lane < lim && (uint32_t)lane + adv <= 63);
@@ -165,12 +175,12 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
     }
     if (M == 0) {
       // ---- the element at `pos` is a literal that does not end inside the slice (or a damaged header): moved on its own ----
-      if (__builtin_amdgcn_readfirstlane((int)bad)) { failed = true; break; }
+      if (__builtin_amdgcn_readfirstlane((int)bad) || (span && span->lead)) { failed = true; break; }
       const uint32_t llen = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
       const uint32_t data = pos + (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr);
       if (llen > dlen - out) { failed = true; break; }
       if (MODE == SN_INDEX) {                     // where the 64 KiB blocks of output start in the input
-        if ((out & 0xffffu) == 0 && lane == 0) index[1 + (out >> 16)] = pos;
+        if (index && (out & 0xffffu) == 0 && lane == 0) index[1 + (out >> 16)] = pos;
         if ((out ^ (out + llen - 1)) >> 16) aligned = false;
       } else {
         uint32_t done = 0;
@@ -213,7 +223,7 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
     const bool copy = start && kind != 0;
     if (__builtin_amdgcn_ballot_w64(start && (bad || opos + len > dlen || (MODE == SN_FULL && kind != 0 && (off == 0 || off > opos))))) { failed = true; break; }
     if (MODE == SN_INDEX) {
-      if (start && (opos & 0xffffu) == 0) index[1 + (opos >> 16)] = pos + (uint32_t)lane;
+      if (index && start && (opos & 0xffffu) == 0) index[1 + (opos >> 16)] = pos + (uint32_t)lane;
       if (__builtin_amdgcn_ballot_w64(start && ((opos ^ (opos + len - 1)) >> 16) != 0)) aligned = false;
     } else {
       // 1. a later element of the batch writes ring slots up to o_end: what lies 64 KiB below that is overwritten.  Copies
@@ -270,27 +280,88 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
       if (out - flushed >= SN_FLUSH) flush(out & ~15u);
     }
   }
-  if (!failed && (out != dlen || pos != slen)) failed = true;
+  if (span) { span->end_pos = pos; span->end_out = out; }
+  if (!failed && (!span || span->whole) && (out != dlen || pos != slen)) failed = true;
   if (MODE == SN_FULL && !failed) flush(out);
   return failed;
 }
 
 }  // namespace
 
-// The INDEX jobs of a launch (one wave each): only the 4 KiB input window in LDS, so these waves do not compete with the
-// BLOCK jobs of other pages for the CUs' LDS (two 64 KiB rings fill a CU).
+// The walks of a launch (one wave each): only the 4 KiB input window in LDS, so these waves do not compete with the BLOCK
+// jobs of other pages for the CUs' LDS (two 64 KiB rings fill a CU).
+//   INDEX    the whole chain of a page, from its first element.
+//   SEG      a LARGE page (its walk would take ~13 ms per MB of compressed bytes) is cut into PQ_SNAPPY_SEGMENTS equal ranges
+//            of input and every range is walked by its own wave.  Where the chain enters a range is not known, so wave w
+//            GUESSES: it starts 2 KiB in front of its range at an arbitrary byte; a chain started at a wrong byte reads
+//            literal bytes as headers but, with element starts a few bytes apart, falls onto a true start within a few
+//            elements and is the true chain from there on.  The wave records where it entered its range (g), where it left
+//            it (e) and how many bytes of output the elements in between make (L).
+//   RESOLVE  the guesses are ACCEPTED only if they prove each other: segment 0 starts at the true beginning, so its exit is
+//            true; g of segment 1 must equal it EXACTLY, which makes segment 1's exit true, and so on.  Then the output
+//            position at which segment w begins is the sum of the L in front of it and the wave walks its range again, this
+//            time noting the block starts.  If any link fails (a guess that never met the chain: long literals, a misread
+//            extended length), segment 0's wave walks the whole page as an INDEX job would.  Nothing is assumed: a wrong
+//            guess costs time, not correctness.
 __global__ __launch_bounds__(64) void pq_inflate_index_kernel(const PqCodecParams p) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[SN_WIN + 32];
   const int lane = threadIdx.x;
   const PqCodecJob job = p.jobs[blockIdx.x];
+  const uint8_t* src = job.raw + job.src_at;
   const uint32_t slen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.src_len), dlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.dst_len);
+  const uint32_t codec = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.codec);
+  const uint32_t nblk = (dlen + 65535u) / 65536u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.block);
+  uint32_t* seg = job.index + nblk + 2;        // [PQ_SNAPPY_SEGMENTS][4]: g, e, L, ok
+  const uint32_t b0 = (uint32_t)((uint64_t)slen * w / PQ_SNAPPY_SEGMENTS);
+  const uint32_t b1 = w + 1 >= PQ_SNAPPY_SEGMENTS ? slen : (uint32_t)((uint64_t)slen * (w + 1) / PQ_SNAPPY_SEGMENTS);
   bool aligned = true;
   uint32_t first4 = 0;
-  const bool failed = snappy_stream<SN_INDEX>(job.raw + job.src_at, slen, nullptr, dlen, true, job.index, aligned, first4, nullptr, s_win, lane);
+  SnappySpan sp{};
+  SnappySpan* use = nullptr;                   // (null: the whole page)
+  uint32_t* table = job.index;
+  uint32_t limit = dlen;
+  bool preamble = true, guessing = false;
+  if (codec == PQ_CODEC_SNAPPY_SEG) {
+    table = nullptr; use = &sp;
+    if (w == 0) { sp.start = 0; sp.stop = b1; }
+    else { sp.start = b0 - PQ_SNAPPY_LEAD; sp.stop = b0; sp.lead = true; guessing = true; preamble = false; limit = 0x7fffffffu; }
+  } else if (codec == PQ_CODEC_SNAPPY_RESOLVE) {
+    bool proven = true;
+    uint32_t before = 0, mine = 0, prev_e = 0;
+    for (uint32_t v = 0; v < PQ_SNAPPY_SEGMENTS; ++v) {
+      const uint32_t g = seg[4 * v], e = seg[4 * v + 1], l = seg[4 * v + 2], ok = seg[4 * v + 3];
+      if (!ok || (v > 0 && g != prev_e)) proven = false;
+      if (v < w) before += l;
+      if (v == w) mine = g;
+      prev_e = e;
+    }
+    proven = __builtin_amdgcn_readfirstlane((int)proven) != 0;
+    if (proven) { use = &sp; sp.start = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine); sp.stop = b1; sp.out0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)before); sp.whole = w + 1 == PQ_SNAPPY_SEGMENTS; preamble = false; }
+    else if (w != 0) return;
+  }
+  bool failed = false, ok = true;
+  uint32_t g = 0;
+  for (int tries = 0;;) {
+    failed = snappy_stream<SN_INDEX>(src, slen, nullptr, limit, preamble, table, aligned, first4, nullptr, s_win, lane, use);
+    if (!guessing) break;
+    if (!failed) {                             // the guess reached its range: now the range itself
+      g = sp.end_pos; guessing = false;
+      sp = SnappySpan{}; sp.start = g; sp.stop = b1;
+      continue;
+    }
+    if (++tries >= 8 || sp.end_pos + 1 >= b0) { ok = false; break; }
+    sp.start = sp.end_pos + 1;                 // behind whatever did not look like an element
+  }
+  if (codec == PQ_CODEC_SNAPPY_SEG) {
+    if (w == 0) g = sp.first;
+    if (lane == 0) { seg[4 * w] = g; seg[4 * w + 1] = sp.end_pos; seg[4 * w + 2] = sp.end_out; seg[4 * w + 3] = ok && !failed ? 1u : 0u; }
+    return;
+  }
   if (job.flags & PQ_JOB_FORCE_FALLBACK) aligned = false;
   if (lane == 0) {
     if (failed || !aligned) job.index[0] = 1u;                        // the page is inflated by its FINISH job
-    else job.index[1 + (dlen + 65535u) / 65536u] = slen;             // (the end of the last block)
+    else if (!use || sp.whole) job.index[1 + nblk] = slen;           // (the end of the last block)
     if (failed) codec_error(job.err);
   }
 }

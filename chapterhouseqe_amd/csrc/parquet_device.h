@@ -46,7 +46,12 @@ enum : uint32_t { PQ_CODEC_STORED = 0, PQ_CODEC_SNAPPY = 1,
                   // a snappy page of several 64 KiB blocks, inflated block by block (parquet_codec.hip): three jobs in three launches
                   PQ_CODEC_SNAPPY_INDEX = 2,    // walks the element chain, writes where every block starts in the input
                   PQ_CODEC_SNAPPY_BLOCK = 3,    // inflates block `block` (one per block of the page)
-                  PQ_CODEC_SNAPPY_FINISH = 4 }; // patches the page descriptor; inflates the whole page if the blocks gave up
+                  PQ_CODEC_SNAPPY_FINISH = 4,   // patches the page descriptor; inflates the whole page if the blocks gave up
+                  // ... and the INDEX walk of a large page as two launches of one wave per SEGMENT of its input (`block` = segment)
+                  PQ_CODEC_SNAPPY_SEG = 5,      // walks a segment from a guessed start; notes where it entered, left, and the output in between
+                  PQ_CODEC_SNAPPY_RESOLVE = 6 };// if the segments' entries and exits chain up exactly: walks the segment again, noting block starts
+constexpr uint32_t PQ_SNAPPY_SEGMENTS = 8;      // (pages of >= 512 KiB of compressed bytes: every segment >= 64 KiB)
+constexpr uint32_t PQ_SNAPPY_LEAD = 2048;       // bytes in front of a segment from where its wave looks for the chain
 enum : uint32_t { PQ_JOB_KEEP_LEVELS = 1,       // with `page`: the column's definition levels are decoded (else only skipped)
                   PQ_JOB_FORCE_FALLBACK = 2 };  // INDEX job: report "not block-aligned" (tests of the FINISH path)
 struct PqCodecJob {
@@ -62,7 +67,8 @@ struct PqCodecJob {
   uint32_t flags;             // PQ_JOB_*
   uint32_t block;             // SNAPPY_BLOCK: which 64 KiB block of the page
   uint32_t* index;            // SNAPPY_INDEX / _BLOCK / _FINISH: [0] != 0: the blocks gave up; [1 + k]: input position of block k;
-                              // [1 + blocks]: the page's compressed length (zero-filled before the launches)
+                              // [1 + blocks]: the page's compressed length; [2 + blocks ...]: PQ_SNAPPY_SEGMENTS x {entered at, left at,
+                              // output bytes, ok} of a segmented walk (zero-filled before the launches)
 };
 // A launch serves every compressed page of every column and row group of a call's wave (jobs carry their own buffers):
 // a page is a serial chain, so the pages (and, after the index walk, their 64 KiB blocks) in flight are the parallelism --

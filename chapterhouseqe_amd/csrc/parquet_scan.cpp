@@ -490,16 +490,15 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
     // of compressed bytes are collected over the whole wave and form ONE more chain on a stream of its own, behind the last
     // upload.  (Their walks all have to run side by side -- in one launch: a chain per part put them behind each other on
     // the few hardware queues the streams share, 33 -> 51 ms for the 20-row-group sample.)
-    struct Chain { std::vector<PqCodecJob> index, blocks, finish; };
+    struct Chain { std::vector<PqCodecJob> seg, index, blocks, finish; size_t words = 0; };   // (words: of the index table)
     std::vector<std::shared_ptr<void>> host_keep;
     std::vector<BufferPtr> device_keep;
     std::vector<hipEvent_t> col_inflated;      // per entry of wave.cols
     const hipStream_t ustream = ctx.aux[Context::kCopyStream];
     auto launch_chain = [&](const Chain& ch, hipStream_t st) -> hipEvent_t {
       auto keep = std::make_shared<std::vector<PqCodecJob>>();
-      for (const std::vector<PqCodecJob>* v : {&ch.index, &ch.blocks, &ch.finish}) keep->insert(keep->end(), v->begin(), v->end());
-      size_t index_words = 0;
-      for (const PqCodecJob& j : ch.index) index_words += (j.dst_len + 65535u) / 65536u + 2;
+      for (const std::vector<PqCodecJob>* v : {&ch.seg, &ch.index, &ch.blocks, &ch.finish}) keep->insert(keep->end(), v->begin(), v->end());
+      const size_t index_words = ch.words;
       if (index_words) {   // (the jobs carry offsets into the table until it exists)
         BufferPtr index_dev = make_device_buffer(index_words * sizeof(uint32_t) + 16, ctx.device);
         check_hip(hipMemsetAsync(index_dev->ptr, 0, index_words * sizeof(uint32_t), ustream), "memset");
@@ -514,30 +513,33 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       check_hip(hipEventRecord(ev_ready, ustream), "hipEventRecord(jobs)");
       check_hip(hipStreamWaitEvent(st, ev_ready, 0), "hipStreamWaitEvent(jobs)");
       const PqCodecJob* at = (const PqCodecJob*)jobs_dev->ptr;
-      const size_t counts[3] = {ch.index.size(), ch.blocks.size(), ch.finish.size()};
-      for (int k = 0; k < 3; ++k) {
+      const size_t counts[4] = {ch.seg.size(), ch.index.size(), ch.blocks.size(), ch.finish.size()};
+      for (int k = 0; k < 4; ++k) {
         PqCodecParams cp{};
         cp.jobs = at; cp.n_jobs = (int32_t)counts[k];
-        check_hip(k == 0 ? pq_launch_inflate_index(cp, st) : pq_launch_inflate(cp, st), "launch pq_inflate_kernel");
+        check_hip(k < 2 ? pq_launch_inflate_index(cp, st) : pq_launch_inflate(cp, st), "launch pq_inflate_kernel");
         at += counts[k];
       }
       const hipEvent_t ev_done = upload_event(ctx, wave.n_events++);
       check_hip(hipEventRecord(ev_done, st), "hipEventRecord(inflate)");
       return ev_done;
     };
-    auto add_page = [&](Chain& ch, const PqCodecJob& j) {   // an indexed page: its INDEX, BLOCK and FINISH jobs
-      size_t index_words = 0;
-      for (const PqCodecJob& q : ch.index) index_words += (q.dst_len + 65535u) / 65536u + 2;
+    auto add_page = [&](Chain& ch, const PqCodecJob& j, bool segments) {   // an indexed page: its INDEX (or SEG + RESOLVE), BLOCK and FINISH jobs
       const uint32_t nblk = (j.dst_len + 65535u) / 65536u;
       PqCodecJob a = j;
-      a.index = (uint32_t*)(uintptr_t)(index_words * sizeof(uint32_t));
+      a.index = (uint32_t*)(uintptr_t)(ch.words * sizeof(uint32_t));   // (an offset until the table exists)
+      ch.words += nblk + 2 + 4 * PQ_SNAPPY_SEGMENTS;
       PqCodecJob c = a; c.codec = PQ_CODEC_SNAPPY_FINISH;
       ch.finish.push_back(c);
       a.page = -1; a.flags = ctx.opt_snappy_blocks == 2 ? PQ_JOB_FORCE_FALLBACK : 0u;
       a.codec = PQ_CODEC_SNAPPY_BLOCK;
       for (uint32_t k = 0; k < nblk; ++k) { a.block = k; ch.blocks.push_back(a); }
-      a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
-      ch.index.push_back(a);
+      if (segments) {   // (the walk of a large page: one wave per segment of its input, twice)
+        for (uint32_t k = 0; k < PQ_SNAPPY_SEGMENTS; ++k) { a.block = k; a.codec = PQ_CODEC_SNAPPY_SEG; ch.seg.push_back(a); a.codec = PQ_CODEC_SNAPPY_RESOLVE; ch.index.push_back(a); }
+      } else {
+        a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
+        ch.index.push_back(a);
+      }
     };
     Chain large;
     const size_t n_parts = jobs.size() >= 12 ? 3 : (jobs.size() >= 6 ? 2 : 1);
@@ -549,7 +551,8 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       for (size_t q = job0; q < wave.jobs.size(); ++q) {
         const PqCodecJob& pj = wave.jobs[q];
         if (ctx.opt_snappy_blocks == 0 || pj.codec != PQ_CODEC_SNAPPY || pj.dst_len < 3u * 65536u) ch.blocks.push_back(pj);
-        else add_page(pj.src_len >= (512u << 10) ? large : ch, pj);
+        else if (pj.src_len >= (512u << 10)) add_page(large, pj, ctx.opt_snappy_blocks != 3);
+        else add_page(ch, pj, false);
       }
       hipEvent_t ev = nullptr;
       if (!ch.blocks.empty()) ev = launch_chain(ch, ctx.aux[(part % 2) * 2]);   // (two streams: a part's INDEX launch next to the BLOCK launch before it)

@@ -249,7 +249,7 @@ def test_snappy_elements_the_batched_parser_must_order(ctx):
         check(raw, ctx)
     # pages of three and more 64 KiB blocks were inflated one wave per block (option snappy_blocks, default 1); the same files
     # with one wave per page (0), and with the blocks giving up so that the FINISH job redoes the page (2)
-    for mode in (0, 2):
+    for mode in (0, 2, 3):                    # (3: large pages walked by one wave instead of one per segment)
         c = chq.Context(0)
         c.set_option("snappy_blocks", mode)
         for raw in files[:2]:
@@ -298,7 +298,7 @@ def test_snappy_random_element_mixes(ctx, seed):
     raw = write_bytes(t, compression="snappy", **kw)
     check(raw, ctx)
     c = chq.Context(0)
-    c.set_option("snappy_blocks", int(seed % 3))
+    c.set_option("snappy_blocks", int(seed % 4))
     check(raw, c)
     c.close()
 
@@ -335,27 +335,30 @@ def test_damaged_snappy_pages_of_several_blocks(ctx):
     n = 300_000
     rng = np.random.default_rng(6)
     t = pa.table({"k": pa.array((np.arange(n) // 3).astype(np.int64)), "s": pa.array(["row %06d of many" % (v % 5000) for v in range(n)])})
-    raw = write_bytes(t, compression="snappy", use_dictionary=False, data_page_size=1 << 20)
-    md = pq.ParquetFile(io.BytesIO(raw)).metadata
     reported = 0
-    for col in range(2):
-        cm = md.row_group(0).column(col)
-        assert cm.total_uncompressed_size > 6 * 65536
-        for frac in (0.01, 0.2, 0.45, 0.7, 0.97):
-            for width in (1, 3, 64):
-                bad = bytearray(raw)
-                at = cm.data_page_offset + 64 + int((cm.total_compressed_size - 200) * frac)
-                bad[at:at + width] = bytes(rng.integers(0, 256, width, dtype=np.uint8))
-                try:
-                    f = chq.ParquetFile(bytes(bad))
-                    got = f.read_row_group(0, ctx=ctx)
-                    assert got.num_rows == n
-                    got.release()
-                except chq.ChqError as e:
-                    assert e.code in (22, 30), str(e)
-                    reported += 1
-    assert reported >= 5
-    check(raw, ctx)
+    for page_size in (1 << 20, 1 << 26):      # (1 << 26: one page per chunk -- the strings' is walked in segments)
+        raw = write_bytes(t, compression="snappy", use_dictionary=False, data_page_size=page_size)
+        md = pq.ParquetFile(io.BytesIO(raw)).metadata
+        if page_size == 1 << 26:
+            assert md.row_group(0).column(1).total_compressed_size > (512 << 10)
+        for col in range(2):
+            cm = md.row_group(0).column(col)
+            assert cm.total_uncompressed_size > 6 * 65536
+            for frac in (0.01, 0.2, 0.45, 0.7, 0.97):
+                for width in (1, 3, 64):
+                    bad = bytearray(raw)
+                    at = cm.data_page_offset + 64 + int((cm.total_compressed_size - 200) * frac)
+                    bad[at:at + width] = bytes(rng.integers(0, 256, width, dtype=np.uint8))
+                    try:
+                        f = chq.ParquetFile(bytes(bad))
+                        got = f.read_row_group(0, ctx=ctx)
+                        assert got.num_rows == n
+                        got.release()
+                    except chq.ChqError as e:
+                        assert e.code in (22, 30), str(e)
+                        reported += 1
+        check(raw, ctx)
+    assert reported >= 10
 
 
 def test_host_result_and_required_columns(ctx):
