@@ -291,8 +291,8 @@ __device__ __forceinline__ bool snappy_stream(const uint8_t* src, const uint32_t
 // The walks of a launch (one wave each): only the 4 KiB input window in LDS, so these waves do not compete with the BLOCK
 // jobs of other pages for the CUs' LDS (two 64 KiB rings fill a CU).
 //   INDEX    the whole chain of a page, from its first element.
-//   SEG      a LARGE page (its walk would take ~13 ms per MB of compressed bytes) is cut into PQ_SNAPPY_SEGMENTS equal ranges
-//            of input and every range is walked by its own wave.  Where the chain enters a range is not known, so wave w
+//   SEG      a page of 64 KiB and more of compressed bytes (a walk takes ~13 ms per MB of them) is cut into up to
+//            PQ_SNAPPY_SEGMENTS equal ranges of at least 32 KiB of input and every range is walked by its own wave.  Where the chain enters a range is not known, so wave w
 //            GUESSES: it starts 2 KiB in front of its range at an arbitrary byte; a chain started at a wrong byte reads
 //            literal bytes as headers but, with element starts a few bytes apart, falls onto a true start within a few
 //            elements and is the true chain from there on.  The wave records where it entered its range (g), where it left
@@ -311,10 +311,11 @@ __global__ __launch_bounds__(64) void pq_inflate_index_kernel(const PqCodecParam
   const uint32_t slen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.src_len), dlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.dst_len);
   const uint32_t codec = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.codec);
   const uint32_t nblk = (dlen + 65535u) / 65536u;
-  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.block);
-  uint32_t* seg = job.index + nblk + 2;        // [PQ_SNAPPY_SEGMENTS][4]: g, e, L, ok
-  const uint32_t b0 = (uint32_t)((uint64_t)slen * w / PQ_SNAPPY_SEGMENTS);
-  const uint32_t b1 = w + 1 >= PQ_SNAPPY_SEGMENTS ? slen : (uint32_t)((uint64_t)slen * (w + 1) / PQ_SNAPPY_SEGMENTS);
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.block & 0xffffu));        // this wave's segment ...
+  const uint32_t n_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(job.block >> 16)) | (codec == PQ_CODEC_SNAPPY_INDEX ? 1u : 0u);   // ... of so many
+  uint32_t* seg = job.index + nblk + 2;        // [n_seg][4]: g, e, L, ok
+  const uint32_t b0 = (uint32_t)((uint64_t)slen * w / n_seg);
+  const uint32_t b1 = w + 1 >= n_seg ? slen : (uint32_t)((uint64_t)slen * (w + 1) / n_seg);
   bool aligned = true;
   uint32_t first4 = 0;
   SnappySpan sp{};
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64) void pq_inflate_index_kernel(const PqCodecParam
   } else if (codec == PQ_CODEC_SNAPPY_RESOLVE) {
     bool proven = true;
     uint32_t before = 0, mine = 0, prev_e = 0;
-    for (uint32_t v = 0; v < PQ_SNAPPY_SEGMENTS; ++v) {
+    for (uint32_t v = 0; v < n_seg; ++v) {
       const uint32_t g = seg[4 * v], e = seg[4 * v + 1], l = seg[4 * v + 2], ok = seg[4 * v + 3];
       if (!ok || (v > 0 && g != prev_e)) proven = false;
       if (v < w) before += l;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(64) void pq_inflate_index_kernel(const PqCodecParam
       prev_e = e;
     }
     proven = __builtin_amdgcn_readfirstlane((int)proven) != 0;
-    if (proven) { use = &sp; sp.start = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine); sp.stop = b1; sp.out0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)before); sp.whole = w + 1 == PQ_SNAPPY_SEGMENTS; preamble = false; }
+    if (proven) { use = &sp; sp.start = (uint32_t)__builtin_amdgcn_readfirstlane((int)mine); sp.stop = b1; sp.out0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)before); sp.whole = w + 1 == n_seg; preamble = false; }
     else if (w != 0) return;
   }
   bool failed = false, ok = true;

@@ -50,7 +50,7 @@ enum : uint32_t { PQ_CODEC_STORED = 0, PQ_CODEC_SNAPPY = 1,
                   // ... and the INDEX walk of a large page as two launches of one wave per SEGMENT of its input (`block` = segment)
                   PQ_CODEC_SNAPPY_SEG = 5,      // walks a segment from a guessed start; notes where it entered, left, and the output in between
                   PQ_CODEC_SNAPPY_RESOLVE = 6 };// if the segments' entries and exits chain up exactly: walks the segment again, noting block starts
-constexpr uint32_t PQ_SNAPPY_SEGMENTS = 8;      // (pages of >= 512 KiB of compressed bytes: every segment >= 64 KiB)
+constexpr uint32_t PQ_SNAPPY_SEGMENTS = 16;     // at most; a segment is at least 32 KiB of compressed bytes (`block` = segment | segments << 16)
 constexpr uint32_t PQ_SNAPPY_LEAD = 2048;       // bytes in front of a segment from where its wave looks for the chain
 enum : uint32_t { PQ_JOB_KEEP_LEVELS = 1,       // with `page`: the column's definition levels are decoded (else only skipped)
                   PQ_JOB_FORCE_FALLBACK = 2 };  // INDEX job: report "not block-aligned" (tests of the FINISH path)

@@ -534,8 +534,9 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
       a.page = -1; a.flags = ctx.opt_snappy_blocks == 2 ? PQ_JOB_FORCE_FALLBACK : 0u;
       a.codec = PQ_CODEC_SNAPPY_BLOCK;
       for (uint32_t k = 0; k < nblk; ++k) { a.block = k; ch.blocks.push_back(a); }
-      if (segments) {   // (the walk of a large page: one wave per segment of its input, twice)
-        for (uint32_t k = 0; k < PQ_SNAPPY_SEGMENTS; ++k) { a.block = k; a.codec = PQ_CODEC_SNAPPY_SEG; ch.seg.push_back(a); a.codec = PQ_CODEC_SNAPPY_RESOLVE; ch.index.push_back(a); }
+      const uint32_t n_seg = segments ? std::min<uint32_t>(PQ_SNAPPY_SEGMENTS, j.src_len >> 15) : 1u;
+      if (n_seg >= 2) {   // (the walk of the page: one wave per segment of its input, twice)
+        for (uint32_t k = 0; k < n_seg; ++k) { a.block = k | (n_seg << 16); a.codec = PQ_CODEC_SNAPPY_SEG; ch.seg.push_back(a); a.codec = PQ_CODEC_SNAPPY_RESOLVE; ch.index.push_back(a); }
       } else {
         a.codec = PQ_CODEC_SNAPPY_INDEX; a.block = 0;
         ch.index.push_back(a);
@@ -552,7 +553,7 @@ std::vector<Batch> parquet_read_row_groups(Context& ctx, const PqFile& f, int fi
         const PqCodecJob& pj = wave.jobs[q];
         if (ctx.opt_snappy_blocks == 0 || pj.codec != PQ_CODEC_SNAPPY || pj.dst_len < 3u * 65536u) ch.blocks.push_back(pj);
         else if (pj.src_len >= (512u << 10)) add_page(large, pj, ctx.opt_snappy_blocks != 3);
-        else add_page(ch, pj, false);
+        else add_page(ch, pj, ctx.opt_snappy_blocks != 3);
       }
       hipEvent_t ev = nullptr;
       if (!ch.blocks.empty()) ev = launch_chain(ch, ctx.aux[(part % 2) * 2]);   // (two streams: a part's INDEX launch next to the BLOCK launch before it)
