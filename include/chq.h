@@ -98,7 +98,8 @@ void* chq_ctx_stream(const chq_ctx* ctx);
  * default 65 536, rounded to multiples of 4 096; a chunk never gets more than 64 pages), "snappy_blocks" (Parquet scan: 1 = a
  * snappy page of three or more 64 KiB blocks is inflated one wave per BLOCK after a walk of its element chain, 0 = one wave
  * per page, 2 = the blocks give up and the page is redone whole -- the path a stream with blocks that depend on each other
- * takes; for tests).  Unknown keys fail.
+ * takes --, 3 = as 1 but every chain walked by one wave instead of one wave per segment of the page's input; 2 and 3 for tests).
+ * Unknown keys fail.
  *
  * Type coverage of expressions = the reference's (RU/compute_value.rs:350-431): the integer / float coercion table,
  * Utf8 and Boolean comparisons, Float16 (widening, f16 arithmetic and comparisons), same-type comparisons of Date32 /
